@@ -190,6 +190,16 @@ enum {
   PGTT_NPARAM = 77
 };
 
+/* Philox4x32-10 stream ids: uniform(seed, env, epoch, stream, i) = top 24 bits of word (i%4) of
+ * philox4x32_10(key = (seed_lo, seed_hi), counter = (global env id, epoch, stream, i/4)) * 2^-24.
+ * `epoch` is istate[PGTT_I_RNG_CTR], incremented once per reset and once per step. */
+enum {
+  PGTT_RS_GYRO = 0, PGTT_RS_GRAVITY = 1, PGTT_RS_QPOS = 2, PGTT_RS_QVEL = 3, PGTT_RS_SCAN = 4,
+  PGTT_RS_CMD_Y = 5, PGTT_RS_CMD_W = 6, PGTT_RS_CMD_Z = 7, PGTT_RS_TIMER = 8,
+  PGTT_RS_RESET_XY = 16, PGTT_RS_RESET_YAW = 17, PGTT_RS_RESET_VEL = 18, PGTT_RS_RESET_TIMER = 19,
+  PGTT_RS_RESET_CMD = 20, PGTT_RS_RESET_FREQ = 21
+};
+
 /* device pointers, all caller-owned, all sized for N = num_envs given to pgtt_create */
 typedef struct PgttBuffers {
   float*   state;        /* [PGTT_NSTATE][N] */

@@ -1,0 +1,234 @@
+"""Physics invariants and hand-derived KATs for the oracle's restatement of the MJX pipeline.
+(The reference ships no tests and its physics engine is not runnable here: parity unpinned, see DESIGN.md.)"""
+import ctypes as C
+import copy
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from phase_guided_terrain_traversal_amd import abi, configs, mjcf
+
+
+def f32_model(task="flat_terrain"):
+    m = mjcf.load_model(task)
+    out = {}
+    for k, v in m.items():
+        out[k] = np.asarray(v, dtype=np.float32).astype(np.float64) if isinstance(v, np.ndarray) and v.dtype.kind == "f" else v
+    return out
+
+
+@pytest.fixture(scope="module")
+def model():
+    return f32_model()
+
+
+def rand_state(rng, m, z=0.6):
+    q = m["key_qpos"].copy()
+    q[0:3] = [rng.uniform(-1, 1), rng.uniform(-1, 1), z]
+    quat = rng.normal(size=4); q[3:7] = quat / np.linalg.norm(quat)
+    q[7:] += rng.uniform(-0.5, 0.5, 12)
+    return q, rng.normal(size=18)
+
+
+def test_kat_mass_and_home_pose(model):
+    assert abs(model["body_mass"].sum() - 15.206408) < 1e-6
+    ms = abi.model_struct(model)
+    d = oracle.forward(ms, model["key_qpos"], np.zeros(18), model["key_qpos"][7:])
+    fp = d["sensordata"][25:37].reshape(4, 3)                     # FR, FL, RR, RL in the imu frame
+    assert np.allclose(fp[0], [0.217727, -0.142, -0.308693], atol=2e-6)
+    assert np.allclose(fp[1], [0.217727, 0.142, -0.308693], atol=2e-6)
+    assert np.allclose(fp[2], [-0.169073, -0.142, -0.308693], atol=2e-6)
+    assert np.allclose(fp[3], [-0.169073, 0.142, -0.308693], atol=2e-6)
+    # plane-sphere distance at the home keyframe: z_foot_centre - r
+    assert np.allclose(d["con_dist"][:4], 0.28 - 0.266373 - 0.0175, atol=2e-6)
+
+
+def test_crba_matches_jacobian_inertia(model):
+    ms = abi.model_struct(model)
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        q, v = rand_state(rng, model)
+        d = oracle.forward(ms, q, v, q[7:])
+        qn = q.copy(); qn[3:7] /= np.linalg.norm(qn[3:7])
+        M = mjcf.mass_matrix_np(model, qn)
+        assert np.abs(d["qM"] - M).max() < 1e-10
+        assert np.allclose(d["qM"], d["qM"].T)
+
+
+def test_free_fall_is_gravity(model):
+    """No contact, qvel = 0, ctrl = q: M^-1(-bias) must be pure gravity on the base and zero elsewhere."""
+    ms = abi.model_struct(model)
+    rng = np.random.default_rng(1)
+    q, _ = rand_state(rng, model, z=1.0)
+    ctrl = np.clip(q[7:], model["act_ctrlrange"][:, 0], model["act_ctrlrange"][:, 1])
+    q[7:] = ctrl[[3, 4, 5, 0, 1, 2, 9, 10, 11, 6, 7, 8]]        # actuator order FR,FL,RR,RL -> joint order
+    d = oracle.forward(ms, q, np.zeros(18), ctrl)
+    assert np.all(d["con_dist"][:4] > 0)
+    assert np.allclose(d["qacc"][:3], [0, 0, -9.81], atol=1e-9)
+    assert np.abs(d["qacc"][3:]).max() < 1e-8
+    assert d["efc_force"].max() == 0
+
+
+def test_energy_conservation_passive(model):
+    """Damping / actuation off, tiny dt, no contact: kinetic + potential energy is conserved by RNE + Euler."""
+    m = copy.deepcopy(model)
+    m["timestep"] = 1e-4
+    m["gravity"] = np.array([0, 0, -9.81])
+    ms = abi.model_struct(m)
+    prm = np.zeros(abi.NPARAM, dtype=np.float32)
+    prm[abi.P_BODY_MASS:abi.P_BODY_MASS + 13] = m["body_mass"]
+    prm[abi.P_BASE_IPOS:abi.P_BASE_IPOS + 3] = m["body_ipos"][0]
+    prm[abi.P_ARMATURE:abi.P_ARMATURE + 12] = m["dof_armature"][6:]
+    prm[abi.P_FLOOR_FRICTION] = 1.0                              # damping, gain, bias1 stay 0
+    rng = np.random.default_rng(2)
+    q, v = rand_state(rng, m, z=5.0)
+    q[3:7] /= np.linalg.norm(q[3:7])
+    v *= 0.5
+    w = np.zeros(18)
+
+    def energy(q, v):
+        M = mjcf.mass_matrix_np(m, q)
+        xipos = mjcf.kinematics_np(m, q)[3]
+        return 0.5 * v @ M @ v + 9.81 * (m["body_mass"] * xipos[:, 2]).sum()
+    e0 = energy(q, v)
+    for _ in range(400):
+        d = oracle.forward(ms, q, v, np.zeros(12), warm=w, params=prm)
+        # act_bias[:,2] (-0.5 kv) is a model constant: compensate by checking only the undamped part
+        q, v, w = d["qpos_next"], d["qvel_next"], d["qacc"]
+    # actuator damping -0.5*qvel dissipates a little; allow for it but catch Coriolis/RNE sign errors (O(1) drift)
+    e1 = energy(q, v)
+    assert e1 <= e0 + 1e-6
+    assert abs(e1 - e0) / abs(e0) < 5e-3
+
+
+def test_com_parabola(model):
+    ms = abi.model_struct(model)
+    rng = np.random.default_rng(3)
+    q, v = rand_state(rng, model, z=5.0)
+    q[3:7] /= np.linalg.norm(q[3:7])
+    w = np.zeros(18)
+    d = oracle.forward(ms, q, v, q[7:])
+    com0 = d["com"].copy()
+    mass = model["body_mass"]
+    # COM velocity from body Jacobians
+    xpos, xquat, xmat, xipos, ximat = mjcf.kinematics_np(model, q)
+    vcom = sum(mass[b] * mjcf.jacobians_np(model, xpos, xmat, xipos[b], b)[0] @ v for b in range(13)) / mass.sum()
+    n, dt = 100, 0.005
+    ctrl = q[7:].copy()
+    for _ in range(n):
+        d = oracle.forward(ms, q, v, ctrl, warm=w)
+        q, v, w = d["qpos_next"], d["qvel_next"], d["qacc"]
+    d = oracle.forward(ms, q, v, ctrl, warm=w)
+    t = n * dt
+    expect = com0 + vcom * t + 0.5 * np.array([0, 0, -9.81]) * t * (t + dt)     # semi-implicit Euler parabola
+    assert np.abs(d["com"] - expect).max() < 2e-3
+
+
+def test_static_stance_force_balance(model):
+    ms = abi.model_struct(model)
+    cs = abi.config_struct(configs.with_overrides(configs.training_config(), **{"noise_config.level": 0.0}))
+    hb = oracle.HostBuffers(1)
+    oracle.reset(cs, ms, None, hb, seed=1, fp64=True)
+    hb["state"][:19, 0] = model["key_qpos"]; hb["state"][19:55, 0] = 0
+    for _ in range(400):
+        oracle.step(cs, ms, None, hb, np.zeros((1, 12)), seed=1, fp64=True)
+    q = hb["state"][:19, 0].astype(np.float64); v = hb["state"][19:37, 0].astype(np.float64)
+    w = hb["state"][37:55, 0].astype(np.float64)
+    d = oracle.forward(ms, q, v, model["key_qpos"][7:], warm=w)
+    normal = d["efc_force"][12:].reshape(8, 4).sum(1)
+    assert abs(normal.sum() - 15.206408 * 9.81) < 0.05            # 149.17 N
+    assert np.abs(v).max() < 0.02
+    assert 0.2 < q[2] < 0.29
+    assert np.all(hb["frame"][abi.F_CONTACT:abi.F_CONTACT + 4, 0] == 1)
+    acc = hb["frame"][abi.F_ACCEL:abi.F_ACCEL + 3, 0]
+    assert abs(np.linalg.norm(acc) - 9.81) < 0.02                 # accelerometer reads the gravity reaction
+
+
+def test_joint_limit_rows(model):
+    ms = abi.model_struct(model)
+    q = model["key_qpos"].copy(); q[2] = 1.0
+    q[7] = model["jnt_range"][0, 1] + 0.05                         # FL hip beyond upper limit
+    q[12] = model["jnt_range"][5, 0] - 0.02                        # FR calf below lower limit
+    v = np.zeros(18); v[6] = 5.0; v[11] = -40.0                    # moving further out: PD alone is not enough
+    d = oracle.forward(ms, q, v, q[7:][[3, 4, 5, 0, 1, 2, 9, 10, 11, 6, 7, 8]])
+    act = d["efc_active"][:12]
+    assert act.tolist() == [1, 0, 0, 0, 0, 1] + [0] * 6
+    assert d["efc_J"][0, 6] == -1 and d["efc_J"][5, 11] == 1
+    assert np.isclose(d["efc_pos"][0], -0.05, atol=1e-6) and np.isclose(d["efc_pos"][5], -0.02, atol=1e-6)
+    assert d["efc_force"][0] > 0 and d["efc_force"][5] > 0
+
+
+def box_row(pos, yaw, size):
+    return np.array([*pos, np.cos(yaw / 2), 0, 0, np.sin(yaw / 2), *size], dtype=np.float32)
+
+
+def test_sphere_box_top_face_and_topk(model):
+    m = f32_model("stairs")
+    ms = abi.model_struct(m)
+    q = m["key_qpos"].copy(); q[2] = 0.28 + 0.10                   # standing on a 0.1 m high platform
+    d0 = oracle.forward(ms, q, np.zeros(18), q[7:])
+    feet = d0["foot_xpos"]
+    boxes = np.tile(box_row([100, 100, 10], 0, [1, 1, 1]), (100, 1))
+    for k in range(100):
+        boxes[k, :3] = [100 + k, 100 + k, 10]
+    boxes[7] = box_row([0, 0, 0.05], np.pi / 2, [1.0, 0.6, 0.05])  # platform under all four feet, rotated 90 deg
+    boxes[3] = box_row([feet[1][0], feet[1][1], 0.052], 0, [0.03, 0.03, 0.052])   # small taller block under FR
+    d = oracle.forward(ms, q, np.zeros(18), q[7:], boxes=boxes)
+    assert np.all(d["con_dist"][:4] > 0)                            # plane is 0.1 m below
+    pairs = sorted(zip(d["con_dist"][4:], d["con_foot"][4:], d["con_box"][4:]))
+    # 5 penetrating pairs exist (4 on the platform + FR on the block); max_contact_points keeps the 4 deepest
+    assert [(f, b) for _, f, b in pairs][0] == (1, 3)
+    assert sum(1 for dist, _, _ in pairs if dist < 0) == 4
+    expect_plat = (0.38 - 0.266373 - 0.0175) - 0.10
+    for dist, f, b in pairs[1:]:
+        assert b == 7 and abs(dist - expect_plat) < 2e-6
+    assert abs(pairs[0][0] - (expect_plat - 0.004)) < 2e-6
+    # normal of a top-face contact points from the sphere into the box: -z
+    k = 4 + int(np.argmin(d["con_dist"][4:]))
+    assert np.allclose(d["con_frame"][k][0], [0, 0, -1], atol=1e-6)
+
+
+def test_scan_matches_box_tops():
+    m = f32_model("stairs")
+    cs = abi.config_struct(configs.default_config())
+    import os
+    terr = np.load(os.path.join(os.path.dirname(mjcf.__file__), "assets", "terrains", "level4.npy"))
+    rng = np.random.default_rng(5)
+    for v in (0, 17, 63):
+        boxes = terr[v]
+        c = np.array([rng.uniform(-3, 3), rng.uniform(-3, 3), 0.4]); yaw = rng.uniform(-3, 3)
+        hit = oracle.scan(cs, boxes, c, yaw, fp64=True).reshape(-1, 3)
+        for p in hit:
+            top = 0.0
+            for b in boxes:
+                ang = 2 * np.arctan2(b[6], b[3])
+                dx, dy = p[0] - b[0], p[1] - b[1]
+                lx, ly = np.cos(ang) * dx + np.sin(ang) * dy, -np.sin(ang) * dx + np.cos(ang) * dy
+                if abs(lx) <= b[7] and abs(ly) <= b[8]:
+                    top = max(top, b[2] + b[9])
+            assert abs(p[2] - top) < 1e-5 or _near_edge(p, boxes)
+
+
+def _near_edge(p, boxes, eps=1e-5):
+    for b in boxes:
+        ang = 2 * np.arctan2(b[6], b[3])
+        dx, dy = p[0] - b[0], p[1] - b[1]
+        lx, ly = np.cos(ang) * dx + np.sin(ang) * dy, -np.sin(ang) * dx + np.cos(ang) * dy
+        if abs(abs(lx) - b[7]) < eps or abs(abs(ly) - b[8]) < eps:
+            return True
+    return False
+
+
+def test_f32_tracks_f64(model):
+    ms = abi.model_struct(model)
+    rng = np.random.default_rng(7)
+    for z in (0.27, 0.6):
+        q, v = rand_state(rng, model, z=z)
+        q[3:7] = [1, 0, 0, 0]
+        a = oracle.forward(ms, q, v * 0.2, q[7:], fp64=True)
+        b = oracle.forward(ms, q, v * 0.2, q[7:], fp64=False)
+        assert np.abs(a["qM"] - b["qM"]).max() < 1e-5
+        assert np.abs(a["qpos_next"] - b["qpos_next"]).max() < 1e-5
+        assert np.abs(a["qvel_next"] - b["qvel_next"]).max() < 2e-3
+        assert np.array_equal(a["efc_active"], b["efc_active"])

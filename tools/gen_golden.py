@@ -1,0 +1,318 @@
+"""Generate golden fixtures by IMPORTING the reference's own Python (THIS container only).
+
+    python tools/gen_golden.py [/root/reference]      ->  tests/golden/*.npz
+
+The reference's task layer (go2/joystick_pgtt.py, go2/gait.py, go2/heightmap.py, go2/utility.py) is
+pure array arithmetic on top of un-installed JAX / MuJoCo-MJX / Playground.  We import it under
+`sys.modules` shims (jax.numpy -> numpy float64, jax.random -> deterministic stubs, mujoco/mjx/
+playground -> empty or recording stubs) and record INPUT/OUTPUT vectors only.  No reference source
+text is stored; the reference is never shipped.  Fixtures:
+
+  gait_get_z.npz     go2.gait.get_z over a phase grid                         (gait.py:27-49)
+  quat_to_yaw.npz    go2.utility.quat_to_yaw (scipy Rotation)                  (utility.py:4-8)
+  scan_grid.npz      go2.heightmap.create_sensor_matrix with mjx.ray stubbed to a constant distance:
+                     records the 13x9 ray origins for (centre, yaw) cases      (heightmap.py:25-67)
+  task_step.npz      Joystick.step executed END TO END with mjx_env.step / create_sensor_matrix /
+                     compute_contact replaced by fakes that return synthetic physics outputs, and
+                     jax.random stubbed (uniform -> 0.5, bernoulli -> 0.5 < p, exponential ->
+                     -log1p(-0.5)):  obs[171], privileged[215], reward, done, 21 metrics and every
+                     info field after the step                                 (joystick_pgtt.py:141-231)
+  task_reset_obs.npz Joystick._get_obs on a reset-like info (history update branch) (joystick_pgtt.py:238-370)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+# ------------------------------------------------------------------ shims
+class _At:
+    def __init__(self, arr):
+        self.arr = arr
+
+    def __getitem__(self, idx):
+        arr = self.arr
+
+        class _Setter:
+            def set(self, v):
+                out = np.array(arr, copy=True).view(AtArray)
+                out[idx] = v
+                return out
+        return _Setter()
+
+
+class AtArray(np.ndarray):
+    @property
+    def at(self):
+        return _At(self)
+
+
+def _wrap(fn):
+    def g(*a, **k):
+        r = fn(*a, **k)
+        return r.view(AtArray) if isinstance(r, np.ndarray) else r
+    return g
+
+
+jnp = types.ModuleType("jax.numpy")
+for name in dir(np):
+    if not name.startswith("_"):
+        obj = getattr(np, name)
+        setattr(jnp, name, _wrap(obj) if callable(obj) and not isinstance(obj, type) else obj)
+jnp.array = lambda x, dtype=None: np.array(x, dtype=dtype or np.float64 if not isinstance(x, np.ndarray) or x.dtype.kind == "f" else None).view(AtArray)
+jnp.ndarray = np.ndarray
+jnp.float32, jnp.int32 = np.float32, np.int32
+jnp.pi = np.pi
+
+
+def _vmap(fn, in_axes=0):
+    def g(*args):
+        axes = in_axes if isinstance(in_axes, (tuple, list)) else (in_axes,) * len(args)
+        n = [np.shape(a)[0] for a, ax in zip(args, axes) if ax is not None][0]
+        outs = [fn(*[a if ax is None else a[i] for a, ax in zip(args, axes)]) for i in range(n)]
+        return np.stack(outs).view(AtArray)
+    return g
+
+
+jrandom = types.ModuleType("jax.random")
+jrandom.split = lambda key, n=2: tuple(key for _ in range(n))
+jrandom.uniform = lambda key, shape=(), minval=0.0, maxval=1.0: (0.5 * (np.asarray(maxval) - np.asarray(minval)) + np.asarray(minval)) * np.ones(shape)
+jrandom.bernoulli = lambda key, p=0.5, shape=(): (0.5 < np.asarray(p)) * np.ones(shape, dtype=bool)
+jrandom.exponential = lambda key, shape=(): -np.log1p(-0.5) * np.ones(shape)
+jrandom.PRNGKey = lambda s: np.zeros(2, dtype=np.uint32)
+
+jax = types.ModuleType("jax")
+jax.numpy, jax.random, jax.Array = jnp, jrandom, np.ndarray
+jax.jit = lambda f=None, **k: (f if f is not None else (lambda g: g))
+jax.vmap = _vmap
+jax.debug = types.SimpleNamespace(print=lambda *a, **k: None)
+jsp = types.ModuleType("jax.scipy"); jsps = types.ModuleType("jax.scipy.spatial"); jspt = types.ModuleType("jax.scipy.spatial.transform")
+from scipy.spatial.transform import Rotation as _Rot
+jspt.Rotation = _Rot
+jax.scipy = jsp; jsp.spatial = jsps; jsps.transform = jspt
+
+
+class AttrDict(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+    def keys(self):
+        return dict.keys(self)
+
+
+def _create(**kw):
+    return AttrDict({k: (_create(**v) if isinstance(v, dict) else v) for k, v in kw.items()})
+
+
+mlc = types.ModuleType("ml_collections"); cdm = types.ModuleType("ml_collections.config_dict")
+cdm.create = _create; cdm.ConfigDict = AttrDict; mlc.config_dict = cdm
+
+mujoco = types.ModuleType("mujoco"); mjx = types.ModuleType("mujoco.mjx")
+mjx_src = types.ModuleType("mujoco.mjx._src"); mjx_math = types.ModuleType("mujoco.mjx._src.math")
+mujoco.mjx = mjx; mjx._src = mjx_src; mjx_src.math = mjx_math
+mjx.Data = object; mjx.Model = object; mujoco.MjModel = object; mujoco.MjData = object
+RAY_DIST = 0.25
+RAY_LOG = []
+
+
+def _ray(m, d, pnt, vec=None, geomgroup=None):
+    RAY_LOG.append(np.array(pnt, dtype=np.float64))
+    return (RAY_DIST, 0)
+
+
+mjx.ray = _ray
+
+mp = types.ModuleType("mujoco_playground"); mps = types.ModuleType("mujoco_playground._src")
+mpe = types.ModuleType("mujoco_playground._src.mjx_env"); mpc = types.ModuleType("mujoco_playground._src.collision")
+mp._src = mps; mps.mjx_env = mpe; mps.collision = mpc
+
+# sensor layout of go2_mjx_feetonly.xml:258-274 (adr, dim) — a fact about the model, cross-checked by mjcf.py
+_dims = dict(gyro=3, accelerometer=3, orientation=4, global_position=3, global_linvel=3, global_angvel=3,
+             local_linvel=3, upvector=3, FR_pos=3, FL_pos=3, RR_pos=3, RL_pos=3, FR_foot_global_linvel=3,
+             FL_foot_global_linvel=3, RR_foot_global_linvel=3, RL_foot_global_linvel=3)
+SENSOR_ADR = {}
+_a = 0
+for _k, _v in _dims.items():
+    SENSOR_ADR[_k] = (_a, _v); _a += _v
+
+
+class MjxEnv:
+    def __init__(self, config=None, config_overrides=None):
+        self._config = config
+
+    @property
+    def dt(self):
+        return self._config.ctrl_dt
+
+    @property
+    def sim_dt(self):
+        return self._config.sim_dt
+
+    @property
+    def n_substeps(self):
+        return int(round(self.dt / self.sim_dt))
+
+
+class State:
+    def __init__(self, data, obs, reward, done, metrics, info):
+        self.data, self.obs, self.reward, self.done, self.metrics, self.info = data, obs, reward, done, metrics, info
+
+    def replace(self, **kw):
+        s = State(self.data, self.obs, self.reward, self.done, self.metrics, self.info)
+        for k, v in kw.items():
+            setattr(s, k, v)
+        return s
+
+
+mpe.MjxEnv = MjxEnv; mpe.State = State
+mpe.get_sensor_data = lambda model, data, name: data.sensordata[SENSOR_ADR[name][0]:SENSOR_ADR[name][0] + SENSOR_ADR[name][1]]
+mpe.update_assets = lambda *a, **k: None
+FAKE = {}
+mpe.step = lambda model, data, ctrl, n: FAKE["data"]
+
+etils = types.ModuleType("etils"); epath = types.ModuleType("etils.epath")
+import pathlib
+epath.Path = pathlib.PurePosixPath; etils.epath = epath
+mpl = types.ModuleType("matplotlib"); mplp = types.ModuleType("matplotlib.pyplot"); mpl.pyplot = mplp
+
+for name, mod in {"jax": jax, "jax.numpy": jnp, "jax.random": jrandom, "jax.scipy": jsp, "jax.scipy.spatial": jsps,
+                  "jax.scipy.spatial.transform": jspt, "ml_collections": mlc, "ml_collections.config_dict": cdm,
+                  "mujoco": mujoco, "mujoco.mjx": mjx, "mujoco.mjx._src": mjx_src, "mujoco.mjx._src.math": mjx_math,
+                  "mujoco_playground": mp, "mujoco_playground._src": mps, "mujoco_playground._src.mjx_env": mpe,
+                  "mujoco_playground._src.collision": mpc, "etils": etils, "etils.epath": epath,
+                  "matplotlib": mpl, "matplotlib.pyplot": mplp}.items():
+    sys.modules[name] = mod
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+import go2.gait as gait                    # noqa: E402
+import go2.utility as utility              # noqa: E402
+import go2.heightmap as heightmap          # noqa: E402
+import go2.joystick_pgtt as jpg            # noqa: E402
+import go2.configs as rconfigs             # noqa: E402
+
+rng = np.random.default_rng(20250704)
+
+# ------------------------------------------------------------------ F1 get_z
+phi = np.concatenate([np.linspace(0, 2 * np.pi, 97), rng.uniform(0, 2 * np.pi, 64), [np.pi, 1.5 * np.pi]])
+h = rng.uniform(-0.25, -0.05, phi.shape)
+smin = np.full(phi.shape, -0.3)
+z = np.asarray(gait.get_z(phi.view(AtArray), swing_height=h, swing_min=smin), dtype=np.float64)
+np.savez(os.path.join(OUT, "gait_get_z.npz"), phi=phi, swing_height=h, swing_min=smin, z=z,
+         kat=np.asarray(gait.get_z(np.arange(9) * np.pi / 4, swing_height=-0.15, swing_min=-0.3)))
+
+# ------------------------------------------------------------------ quat_to_yaw
+q = rng.normal(size=(256, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+yaw = np.array([float(utility.quat_to_yaw(x)) for x in q])
+np.savez(os.path.join(OUT, "quat_to_yaw.npz"), quat=q, yaw=yaw)
+
+# ------------------------------------------------------------------ F3 scan grid
+centers = rng.uniform(-2, 2, size=(6, 3)); centers[:, 2] = rng.uniform(0.2, 0.5, 6)
+yaws = np.array([0.0, 0.3, -1.2, 3.0, np.pi / 2, -2.5])
+origins, hits = [], []
+for c, y in zip(centers, yaws):
+    RAY_LOG.clear()
+    out = heightmap.create_sensor_matrix(None, None, c, y)
+    origins.append(np.array(RAY_LOG).reshape(13, 9, 3)); hits.append(np.asarray(out))
+np.savez(os.path.join(OUT, "scan_grid.npz"), centers=centers, yaws=yaws, origins=np.array(origins), hits=np.array(hits),
+         ray_dist=RAY_DIST)
+
+# ------------------------------------------------------------------ task step end-to-end with fake physics
+cfg = rconfigs.default_config()
+cfg.command_config.u_max = [0.6, 0.6, 1.0]; cfg.command_config.u_min = [-0.6, -0.6, -1.0]; cfg.gait_freq = [1, 3]   # train.py:127-129
+default_pose = np.array([0, 0.9, -1.8] * 4, dtype=np.float64)
+jnt_range = np.array([[-1.0472, 1.0472], [-1.5708, 3.4907], [-2.7227, -0.83776]] * 4)
+
+
+def make_env():
+    env = object.__new__(jpg.Joystick)
+    env._config = cfg
+    env._default_pose = default_pose.view(AtArray)
+    env._weights = np.array([1.0, 0.1, 0.1] * 4)
+    env._soft_lowers = jnt_range[:, 0] * cfg.soft_joint_pos_limit_factor
+    env._soft_uppers = jnt_range[:, 1] * cfg.soft_joint_pos_limit_factor
+    env._cmd_u_max = np.array(cfg.command_config.u_max); env._cmd_u_min = np.array(cfg.command_config.u_min)
+    env._cmd_b = np.array(cfg.command_config.b)
+    env._imu_site_id = 0
+    env._feet_site_id = np.array([2, 1, 4, 3])          # FR,FL,RR,RL of sites [imu, FL, FR, RL, RR]
+    env._foot_linvel_sensor_adr = np.array([list(range(SENSOR_ADR[f"{s}_foot_global_linvel"][0], SENSOR_ADR[f"{s}_foot_global_linvel"][0] + 3))
+                                            for s in ("FR", "FL", "RR", "RL")])
+    env._torso_body_id = 1
+    env.init_feet_pos = np.zeros((4, 3))
+    env._mj_model = None; env._mjx_model = None
+    env._feet_geom_id = np.arange(4); env._floor_geom_id = np.arange(1)
+    return env
+
+
+class FakeData:
+    pass
+
+
+cases = []
+for case in range(12):
+    env = make_env()
+    d = FakeData()
+    d.qpos = np.concatenate([rng.uniform(-1, 1, 3), rng.normal(size=4), default_pose + rng.uniform(-0.6, 0.6, 12)]).view(AtArray)
+    d.qpos[3:7] /= np.linalg.norm(d.qpos[3:7])
+    if case == 3:   # push joints past the soft limits
+        d.qpos[7:] = np.where(rng.uniform(size=12) < 0.5, jnt_range[:, 0] - 0.01, jnt_range[:, 1] + 0.02)
+    d.qvel = rng.normal(size=18).view(AtArray)
+    d.sensordata = rng.normal(size=49)
+    d.sensordata[25:37] = np.tile([0.2, 0.14, -0.3], 4) + rng.normal(size=12) * 0.05   # feet pos in imu frame
+    if case == 5:
+        d.sensordata[24] = -0.2      # upvector z < 0 -> done
+    Rm = _Rot.from_quat(rng.normal(size=4)).as_matrix()
+    d.site_xmat = np.stack([Rm] + [np.eye(3)] * 4)
+    d.site_xpos = rng.uniform(-1, 1, size=(5, 3))
+    d.actuator_force = rng.uniform(-24, 24, 12)
+    d.xfrc_applied = np.zeros((14, 6))
+    contact = rng.uniform(size=4) < 0.5
+    scan = np.zeros((13, 9, 3)); scan[..., 2] = np.round(rng.uniform(0, 0.3, (13, 9)), 2) * (rng.uniform(size=(13, 9)) < 0.6)
+    FAKE["data"] = d
+    jpg.create_sensor_matrix = lambda mx, dx, center, yaw=0.0, scan=scan: scan.view(AtArray)
+    env.compute_contact = lambda data, a, b, contact=contact: contact
+    env.get_yaw = lambda data: 0.0
+    step0 = int(rng.integers(0, 12)) if case != 1 else 10       # case 1: history-update branch (step % 5 == 0)
+    timer = int(rng.integers(-1, 4)) if case not in (2,) else 1  # case 2: timer expires exactly (1 -> 0)
+    info = {
+        "rng": np.zeros(2, dtype=np.uint32),
+        "command": rng.uniform(-0.6, 0.6, 3) * (0.0 if case == 4 else 1.0),   # case 4: zero command
+        "step": step0, "steps_until_next_cmd": timer,
+        "phase": rng.uniform(0, 2 * np.pi, 4), "phase_dt": 2 * np.pi * 0.02 * 2.0, "gait_freq": 2.0,
+        "last_act": rng.uniform(-1, 1, 12), "last_last_act": rng.uniform(-1, 1, 12),
+        "feet_air_time": rng.uniform(0, 0.3, 4) * (rng.uniform(size=4) < 0.7),
+        "last_contact": rng.uniform(size=4) < 0.5, "swing_peak": -rng.uniform(0, 0.1, 4) * (rng.uniform(size=4) < 0.5),
+        "H_max": 0.1 * np.ones(4), "heightscan": scan, "H_min": np.zeros(4), "motor_targets": np.zeros(12),
+        "qpos_error_history": rng.normal(size=24), "qvel_history": rng.normal(size=24),
+    }
+    metrics = {f"reward/{k}": 0.0 for k in cfg.reward_config.scales.keys()}
+    metrics["swing_peak"] = 0.0
+    info_in = {k: np.array(v, dtype=np.float64) for k, v in info.items() if k not in ("rng", "heightscan")}
+    action = np.tanh(rng.normal(size=12) * 0.6)
+    state = State(FakeData(), None, 0.0, 0.0, metrics, info)
+    out = env.step(state, action.view(AtArray))
+    rec = dict(
+        qpos=np.asarray(d.qpos), qvel=np.asarray(d.qvel), sensordata=d.sensordata, site_imu_mat=Rm,
+        site_foot_z=d.site_xpos[env._feet_site_id][:, 2], actuator_force=d.actuator_force, action=action,
+        scan_z=scan[..., 2].ravel(), contact=contact.astype(np.int32),
+        obs=np.asarray(out.obs["state"], dtype=np.float64), priv=np.asarray(out.obs["privileged_state"], dtype=np.float64),
+        reward=float(out.reward), done=float(out.done),
+        metrics=np.array([float(out.metrics[f"reward/{k}"]) for k in
+                          ["tracking_lin_vel", "tracking_ang_vel", "lin_vel_z", "ang_vel_xy", "orientation", "dof_pos_limits",
+                           "pose", "termination", "stand_still", "torques", "action_rate", "energy", "feet_clearance",
+                           "feet_height", "feet_slip", "feet_air_time", "feet_phase", "feet_swing", "body_height", "contact",
+                           "center"]] + [float(out.metrics["swing_peak"])]),
+    )
+    for k, v in info_in.items():
+        rec["in_" + k] = v
+    for k, v in out.info.items():
+        if k not in ("rng", "heightscan"):
+            rec["out_" + k] = np.array(v, dtype=np.float64)
+    cases.append(rec)
+np.savez(os.path.join(OUT, "task_step.npz"), **{f"c{i}_{k}": v for i, r in enumerate(cases) for k, v in r.items()}, ncases=len(cases))
+print("wrote", sorted(os.listdir(OUT)))
