@@ -205,7 +205,7 @@ typedef struct PgttBuffers {
   float*   state;        /* [PGTT_NSTATE][N] */
   int32_t* istate;       /* [PGTT_NISTATE][N] */
   float*   frame;        /* [PGTT_NFRAME][N] */
-  float*   scan_z;       /* [PGTT_NSCAN][N] hit heights (info["heightscan"][...,2]) */
+  float*   scan_z;       /* [N][PGTT_NSCAN] hit heights (info["heightscan"][...,2]), row-major 13x9 */
   float*   obs_state;    /* [N][PGTT_OBS]   row-major, as the trainer consumes it */
   float*   obs_priv;     /* [N][PGTT_PRIV] */
   float*   reward;       /* [N] */

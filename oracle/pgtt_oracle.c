@@ -235,7 +235,7 @@ typedef struct PgttOraclePostIn {
     for (int i = 0; i < 12; i++) { in->last_act[i] = (RT)S[(PGTT_S_LAST_ACT + i)*N + e];                                 \
       in->last_last_act[i] = (RT)S[(PGTT_S_LAST_LAST_ACT + i)*N + e]; in->motor_targets[i] = (RT)S[(PGTT_S_MOTOR_TARGETS + i)*N + e]; } \
     for (int i = 0; i < 24; i++) { in->qerr_hist[i] = (RT)S[(PGTT_S_QERR_HIST + i)*N + e]; in->qvel_hist[i] = (RT)S[(PGTT_S_QVEL_HIST + i)*N + e]; } \
-    for (int i = 0; i < PGTT_NSCAN; i++) in->scan_z[i] = (RT)B->scan_z[(long)i*N + e];                                   \
+    for (int i = 0; i < PGTT_NSCAN; i++) in->scan_z[i] = (RT)B->scan_z[e*PGTT_NSCAN + i];                                   \
     in->step = I[PGTT_I_STEP*N + e]; in->steps_until_next_cmd = I[PGTT_I_STEPS_UNTIL_CMD*N + e];                         \
     in->rng_ctr = (uint32_t)I[PGTT_I_RNG_CTR*N + e]; in->ep_steps = I[PGTT_I_EP_STEPS*N + e];                            \
   }                                                                                                                      \
@@ -251,7 +251,7 @@ typedef struct PgttOraclePostIn {
     for (int i = 0; i < 12; i++) { S[(PGTT_S_LAST_ACT + i)*N + e] = (float)in->last_act[i];                              \
       S[(PGTT_S_LAST_LAST_ACT + i)*N + e] = (float)in->last_last_act[i]; S[(PGTT_S_MOTOR_TARGETS + i)*N + e] = (float)in->motor_targets[i]; } \
     for (int i = 0; i < 24; i++) { S[(PGTT_S_QERR_HIST + i)*N + e] = (float)in->qerr_hist[i]; S[(PGTT_S_QVEL_HIST + i)*N + e] = (float)in->qvel_hist[i]; } \
-    for (int i = 0; i < PGTT_NSCAN; i++) B->scan_z[(long)i*N + e] = (float)in->scan_z[i];                                \
+    for (int i = 0; i < PGTT_NSCAN; i++) B->scan_z[e*PGTT_NSCAN + i] = (float)in->scan_z[i];                                \
     I[PGTT_I_STEP*N + e] = in->step; I[PGTT_I_STEPS_UNTIL_CMD*N + e] = in->steps_until_next_cmd;                         \
     I[PGTT_I_RNG_CTR*N + e] = (int32_t)in->rng_ctr; I[PGTT_I_EP_STEPS*N + e] = in->ep_steps;                             \
   }                                                                                                                      \

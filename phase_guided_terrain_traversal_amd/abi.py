@@ -79,7 +79,7 @@ class PgttBuffers(C.Structure):
 # (name, rows-or-cols, dtype, layout) ; layout "soa" => [rows][N], "aos" => [N][cols]
 BUFFER_SPECS = [
     ("state", NSTATE, np.float32, "soa"), ("istate", NISTATE, np.int32, "soa"),
-    ("frame", NFRAME, np.float32, "soa"), ("scan_z", NSCAN, np.float32, "soa"),
+    ("frame", NFRAME, np.float32, "soa"), ("scan_z", NSCAN, np.float32, "aos"),
     ("obs_state", OBS, np.float32, "aos"), ("obs_priv", PRIV, np.float32, "aos"),
     ("reward", 1, np.float32, "vec"), ("done", 1, np.float32, "vec"),
     ("metrics", NMETRIC, np.float32, "soa"), ("first_state", S_CMD, np.float32, "soa"),

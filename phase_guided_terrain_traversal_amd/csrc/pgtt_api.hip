@@ -1,0 +1,252 @@
+// pgtt_api.hip — host side of libpgtt.so: the C ABI declared in include/pgtt.h.
+// There is NO CPU fallback: every entry point that computes needs a HIP device and fails with
+// PGTT_E_NODEVICE / PGTT_E_HIP otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pgtt_kernels.hip.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) return fail(PGTT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+}  // namespace
+
+struct pgtt_env {
+  int device = 0;
+  int N = 0;
+  PgttConfig cfg{};
+  PgttModel model{};
+  PgttConfig* d_cfg = nullptr;
+  PgttModel* d_model = nullptr;
+  pgtt::TerrainBox* d_terrain = nullptr;
+  int T = 0, B = 0;
+  PgttBuffers buf{};
+  bool bound = false;
+  unsigned long long seed = 0;
+  long long env_off = 0;
+  bool timing = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool ev_valid = false;
+};
+
+namespace {
+
+pgtt::KArgs make_args(pgtt_env* h, const unsigned char* mask, float yaw_override) {
+  pgtt::KArgs a;
+  a.model = h->d_model; a.cfg = h->d_cfg; a.terrain = h->d_terrain; a.T = h->T; a.B = h->B;
+  a.buf = h->buf; a.N = h->N; a.seed = h->seed; a.env_off = h->env_off; a.mask = mask; a.yaw_override = yaw_override; a.write_qpos = 0;
+  return a;
+}
+
+// the eight physics_kernel instantiations live in their own translation units (pgtt_physics_inst.hip,
+// compiled in parallel); this file only sees their host launchers
+#define PG_DECL(M, D, T) void pgtt_launch_physics_##M##_##D##_##T(int nblocks, hipStream_t st, const pgtt::KArgs& a, const float* action);
+PG_DECL(0, 0, 0) PG_DECL(0, 0, 1) PG_DECL(0, 1, 0) PG_DECL(0, 1, 1) PG_DECL(1, 0, 0) PG_DECL(1, 0, 1) PG_DECL(1, 1, 0) PG_DECL(1, 1, 1)
+#undef PG_DECL
+
+template <int MODE>
+void launch_physics(pgtt_env* h, const pgtt::KArgs& a, const float* action, hipStream_t st) {
+  const int nb = (h->N + 63) / 64;
+  const bool dr = h->buf.params != nullptr, terr = h->T > 0;
+  if (MODE == 0) {
+    if (dr && terr) pgtt_launch_physics_0_1_1(nb, st, a, action); else if (dr) pgtt_launch_physics_0_1_0(nb, st, a, action);
+    else if (terr) pgtt_launch_physics_0_0_1(nb, st, a, action); else pgtt_launch_physics_0_0_0(nb, st, a, action);
+  } else {
+    if (dr && terr) pgtt_launch_physics_1_1_1(nb, st, a, action); else if (dr) pgtt_launch_physics_1_1_0(nb, st, a, action);
+    else if (terr) pgtt_launch_physics_1_0_1(nb, st, a, action); else pgtt_launch_physics_1_0_0(nb, st, a, action);
+  }
+}
+
+template <int OMODE>
+void launch_observe(pgtt_env* h, const pgtt::KArgs& a, const float* action, hipStream_t st) {
+  dim3 grid(h->N), block(64);
+  if (h->T > 0) hipLaunchKernelGGL((pgtt::observe_kernel<OMODE, true>), grid, block, 0, st, a, action);
+  else hipLaunchKernelGGL((pgtt::observe_kernel<OMODE, false>), grid, block, 0, st, a, action);
+}
+
+int check_ready(pgtt_env* h) {
+  if (!h) return fail(PGTT_E_ARG, "null handle");
+  if (!h->bound) return fail(PGTT_E_STATE, "pgtt_bind must be called before reset/step");
+  return PGTT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pgtt_last_error(void) { return g_err.c_str(); }
+const char* pgtt_version(void) { return "pgtt-mi355x 0.1 (gfx950)"; }
+int pgtt_sizeof_model(void) { return (int)sizeof(PgttModel); }
+int pgtt_sizeof_config(void) { return (int)sizeof(PgttConfig); }
+int pgtt_sizeof_buffers(void) { return (int)sizeof(PgttBuffers); }
+
+int pgtt_create(const PgttConfig* cfg, const PgttModel* model, int device, int num_envs, pgtt_handle* out) {
+  if (!cfg || !model || !out) return fail(PGTT_E_ARG, "pgtt_create: null argument");
+  if (num_envs <= 0) return fail(PGTT_E_ARG, "pgtt_create: num_envs must be positive");
+  if (cfg->n_substeps < 1 || cfg->n_substeps > 64) return fail(PGTT_E_ARG, "pgtt_create: n_substeps out of range");
+  static const int expect_dof[12] = {9, 10, 11, 6, 7, 8, 15, 16, 17, 12, 13, 14};
+  for (int a = 0; a < 12; a++)
+    if (model->act_dof[a] != expect_dof[a]) return fail(PGTT_E_ARG, "pgtt_create: actuators must be declared FR,FL,RR,RL on joints FL,FR,RL,RR");
+  for (int b = 1; b < 13; b++)
+    if (model->body_quat[b][0] != 1.f || model->body_quat[b][1] != 0.f || model->body_quat[b][2] != 0.f || model->body_quat[b][3] != 0.f)
+      return fail(PGTT_E_ARG, "pgtt_create: link frames must be unrotated (body_quat = 1 0 0 0)");
+  if (model->foot_friction[0] != model->foot_friction[0]) return fail(PGTT_E_ARG, "pgtt_create: NaN in model");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PGTT_E_NODEVICE, "pgtt_create: no HIP device (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(PGTT_E_ARG, "pgtt_create: device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  pgtt_env* h = new pgtt_env();
+  h->device = device; h->N = num_envs; h->cfg = *cfg; h->model = *model;
+  HIP_TRY(hipMalloc(&h->d_cfg, sizeof(PgttConfig)));
+  HIP_TRY(hipMalloc(&h->d_model, sizeof(PgttModel)));
+  HIP_TRY(hipMemcpy(h->d_cfg, cfg, sizeof(PgttConfig), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_model, model, sizeof(PgttModel), hipMemcpyHostToDevice));
+  for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&h->ev[i]));
+  *out = h;
+  return PGTT_OK;
+}
+
+int pgtt_destroy(pgtt_handle h) {
+  if (!h) return PGTT_OK;
+  hipSetDevice(h->device);
+  if (h->d_cfg) hipFree(h->d_cfg);
+  if (h->d_model) hipFree(h->d_model);
+  if (h->d_terrain) hipFree(h->d_terrain);
+  for (int i = 0; i < 4; i++) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+  delete h;
+  return PGTT_OK;
+}
+
+int pgtt_set_terrain(pgtt_handle h, const float* boxes, int T, int B) {
+  if (!h) return fail(PGTT_E_ARG, "null handle");
+  if (T < 0 || B < 0 || B > PGTT_MAX_BOX) return fail(PGTT_E_ARG, "pgtt_set_terrain: need 0 <= B <= 100, T >= 0");
+  if (T > 0 && (!boxes || B == 0)) return fail(PGTT_E_ARG, "pgtt_set_terrain: null table");
+  HIP_TRY(hipSetDevice(h->device));
+  if (h->d_terrain) { HIP_TRY(hipFree(h->d_terrain)); h->d_terrain = nullptr; }
+  h->T = 0; h->B = 0;
+  if (T == 0) return PGTT_OK;
+  std::vector<pgtt::TerrainBox> tab((size_t)T * B);
+  for (size_t i = 0; i < tab.size(); i++) {
+    const float* r = boxes + 10 * i;
+    pgtt::TerrainBox& t = tab[i];
+    t.px = r[0]; t.py = r[1]; t.pz = r[2];
+    const float w = r[3], x = r[4], y = r[5], z = r[6];
+    // rotation matrix exactly as the simulator's quat_to_mat (no normalisation), plain fp32 ops
+    volatile float q00 = w * w, q01 = w * x, q02 = w * y, q03 = w * z, q11 = x * x, q12 = x * y, q13 = x * z;
+    volatile float q22 = y * y, q23 = y * z, q33 = z * z;
+    volatile float a0 = q00 + q11; volatile float a1 = a0 - q22; t.m00 = a1 - q33;
+    volatile float d0 = q12 - q03; t.m01 = 2.f * d0;
+    volatile float d1 = q13 + q02; t.m02 = 2.f * d1;
+    volatile float d2 = q12 + q03; t.m10 = 2.f * d2;
+    volatile float b0 = q00 - q11; volatile float b1 = b0 + q22; t.m11 = b1 - q33;
+    volatile float d3 = q23 - q01; t.m12 = 2.f * d3;
+    volatile float d4 = q13 - q02; t.m20 = 2.f * d4;
+    volatile float d5 = q23 + q01; t.m21 = 2.f * d5;
+    volatile float c1 = b0 - q22; t.m22 = c1 + q33;
+    t.sx = r[7]; t.sy = r[8]; t.sz = r[9];
+    t.rb = std::sqrt(r[7] * r[7] + r[8] * r[8] + r[9] * r[9]) * 1.000001f;
+  }
+  HIP_TRY(hipMalloc(&h->d_terrain, tab.size() * sizeof(pgtt::TerrainBox)));
+  HIP_TRY(hipMemcpy(h->d_terrain, tab.data(), tab.size() * sizeof(pgtt::TerrainBox), hipMemcpyHostToDevice));
+  h->T = T; h->B = B;
+  return PGTT_OK;
+}
+
+int pgtt_bind(pgtt_handle h, const PgttBuffers* b) {
+  if (!h || !b) return fail(PGTT_E_ARG, "pgtt_bind: null argument");
+  if (!b->state || !b->istate || !b->frame || !b->scan_z || !b->obs_state || !b->obs_priv || !b->reward || !b->done || !b->metrics)
+    return fail(PGTT_E_ARG, "pgtt_bind: state, istate, frame, scan_z, obs_state, obs_priv, reward, done, metrics are required");
+  if (h->cfg.autoreset && (!b->first_state || !b->first_obs))
+    return fail(PGTT_E_ARG, "pgtt_bind: autoreset needs first_state and first_obs");
+  h->buf = *b;
+  h->bound = true;
+  return PGTT_OK;
+}
+
+int pgtt_reset(pgtt_handle h, uint64_t seed, int64_t env_id_offset, const uint8_t* mask, void* stream) {
+  if (int rc = check_ready(h)) return rc;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  h->seed = seed; h->env_off = env_id_offset;
+  pgtt::KArgs a = make_args(h, mask, 0.f);
+  dim3 grid((h->N + 63) / 64), block(64);
+  hipLaunchKernelGGL(pgtt::reset_pose_kernel<0>, grid, block, 0, st, a);
+  launch_physics<pgtt::MODE_FORWARD>(h, a, nullptr, st);          // mjx_env.init -> forward
+  launch_observe<pgtt::OBS_SCAN_LIFT>(h, a, nullptr, st);         // lift by the max terrain height under the footprint
+  a.write_qpos = 1;
+  launch_physics<pgtt::MODE_FORWARD>(h, a, nullptr, st);          // mjx.forward on the lifted pose
+  launch_observe<pgtt::OBS_RESET>(h, a, nullptr, st);             // info, obs, first-state capture
+  HIP_TRY(hipGetLastError());
+  return PGTT_OK;
+}
+
+int pgtt_physics(pgtt_handle h, const float* action, void* stream) {
+  if (int rc = check_ready(h)) return rc;
+  if (!action) return fail(PGTT_E_ARG, "pgtt_physics: null action");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  pgtt::KArgs a = make_args(h, nullptr, 0.f);
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], st));
+  launch_physics<pgtt::MODE_STEP>(h, a, action, st);
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[1], st));
+  HIP_TRY(hipGetLastError());
+  return PGTT_OK;
+}
+
+int pgtt_observe(pgtt_handle h, const float* action, void* stream) {
+  if (int rc = check_ready(h)) return rc;
+  if (!action) return fail(PGTT_E_ARG, "pgtt_observe: null action");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  pgtt::KArgs a = make_args(h, nullptr, 0.f);
+  if (h->timing) HIP_TRY(hipEventRecord(h->ev[2], st));
+  launch_observe<pgtt::OBS_STEP>(h, a, action, st);
+  if (h->timing) { HIP_TRY(hipEventRecord(h->ev[3], st)); h->ev_valid = true; }
+  HIP_TRY(hipGetLastError());
+  return PGTT_OK;
+}
+
+int pgtt_step(pgtt_handle h, const float* action, void* stream) {
+  if (int rc = pgtt_physics(h, action, stream)) return rc;
+  return pgtt_observe(h, action, stream);
+}
+
+int pgtt_scan(pgtt_handle h, float yaw_override_or_nan, void* stream) {
+  if (int rc = check_ready(h)) return rc;
+  HIP_TRY(hipSetDevice(h->device));
+  pgtt::KArgs a = make_args(h, nullptr, yaw_override_or_nan);
+  launch_observe<pgtt::OBS_SCAN_ONLY>(h, a, nullptr, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return PGTT_OK;
+}
+
+int pgtt_enable_timing(pgtt_handle h, int enable) {
+  if (!h) return fail(PGTT_E_ARG, "null handle");
+  h->timing = enable != 0; h->ev_valid = false;
+  return PGTT_OK;
+}
+
+int pgtt_last_kernel_ms(pgtt_handle h, float* physics_ms, float* observe_ms) {
+  if (!h || !physics_ms || !observe_ms) return fail(PGTT_E_ARG, "pgtt_last_kernel_ms: null argument");
+  if (!h->timing || !h->ev_valid) return fail(PGTT_E_STATE, "pgtt_last_kernel_ms: timing not enabled or no step recorded");
+  HIP_TRY(hipEventSynchronize(h->ev[3]));
+  HIP_TRY(hipEventElapsedTime(physics_ms, h->ev[0], h->ev[1]));
+  HIP_TRY(hipEventElapsedTime(observe_ms, h->ev[2], h->ev[3]));
+  return PGTT_OK;
+}
+
+}  // extern "C"

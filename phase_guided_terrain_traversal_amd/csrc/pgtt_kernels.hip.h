@@ -1,0 +1,595 @@
+// pgtt_kernels.hip.h — __global__ kernels of libpgtt.so (gfx950).
+//
+//   physics_kernel  : one env per lane (64-thread blocks).  MODE_STEP = mjx_env.step (n_substeps x
+//                     {forward, Euler}) + sensor frame + contact flags; MODE_FORWARD = one mjx.forward
+//                     (reset path).  Reference: go2/joystick_pgtt.py:146-148, :72, :78.
+//   observe_kernel  : one env per WAVE.  13x9 height scan with the terrain variant's boxes read through
+//                     wave-uniform addresses, quadrant statistics by wave reductions, the 171/215-dim
+//                     observation rows assembled in LDS and stored coalesced, 21 rewards, bookkeeping,
+//                     and (optionally) the Episode/AutoReset wrapper semantics.
+//                     Reference: go2/joystick_pgtt.py:156-231, :238-370, go2/heightmap.py:25-67.
+//   reset_pose_kernel: pose / velocity sampling of Joystick.reset (go2/joystick_pgtt.py:51-70).
+#pragma once
+#include "pgtt_physics.hip.h"
+
+namespace pgtt {
+
+struct KArgs {
+  const PgttModel* model;
+  const PgttConfig* cfg;
+  const TerrainBox* terrain;   // [T][B]
+  int T, B;
+  PgttBuffers buf;
+  int N;
+  unsigned long long seed;
+  long long env_off;
+  const unsigned char* mask;
+  float yaw_override;          // NaN = use the base yaw
+  int write_qpos;              // MODE_FORWARD: store the (quaternion-normalised) qpos
+};
+
+// ------------------------------------------------------------------ Philox4x32-10 (independent of the oracle's C)
+PG_INL void philox4x32_10(unsigned k0, unsigned k1, unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    unsigned h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    unsigned h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    unsigned n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+PG_INL float rng_uniform(unsigned long long seed, unsigned env, unsigned epoch, unsigned stream, int idx) {
+  unsigned c0 = env, c1 = epoch, c2 = stream, c3 = (unsigned)(idx >> 2);
+  philox4x32_10((unsigned)seed, (unsigned)(seed >> 32), c0, c1, c2, c3);
+  unsigned w = (idx & 3) == 0 ? c0 : ((idx & 3) == 1 ? c1 : ((idx & 3) == 2 ? c2 : c3));
+  return (float)(w >> 8) * (1.0f / 16777216.0f);
+}
+PG_INL int exp_timer(unsigned long long seed, unsigned env, unsigned epoch, unsigned stream, float ctrl_dt) {
+  double u = (double)rng_uniform(seed, env, epoch, stream, 0);
+  double t = -log1p(-u) * 5.0;
+  return (int)rint(t / (double)ctrl_dt);
+}
+
+enum { MODE_STEP = 0, MODE_FORWARD = 1 };
+
+// ------------------------------------------------------------------ physics
+template <int MODE, bool HAS_DR, bool HAS_TERRAIN>
+__global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __restrict__ action) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  const int N = a.N;
+  if (e >= N) return;
+  if (MODE != MODE_STEP && a.mask && !a.mask[e]) return;
+  const PgttModel* __restrict__ m = a.model;
+  const PgttConfig* __restrict__ cfg = a.cfg;
+  float* __restrict__ S = a.buf.state;
+
+  EnvModel em;
+  load_env_model<HAS_DR>(m, a.buf.params, N, e, em);
+  Sim s;
+#pragma unroll
+  for (int i = 0; i < 19; i++) s.qpos[i] = S[(PGTT_S_QPOS + i) * (long)N + e];
+#pragma unroll
+  for (int i = 0; i < 18; i++) { s.qvel[i] = S[(PGTT_S_QVEL + i) * (long)N + e]; s.warm[i] = S[(PGTT_S_QWARM + i) * (long)N + e]; }
+  if (MODE == MODE_STEP) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s.ctrl[i] = m->key_qpos[7 + i] + action[(long)e * 12 + i] * cfg->action_scale;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s.ctrl[i] = s.qpos[7 + i];      // mjx_env.init(ctrl = qpos[7:])
+  }
+  const TerrainBox* boxes = nullptr;
+  int nbox = 0;
+  if (HAS_TERRAIN) {
+    int v = a.buf.variant ? a.buf.variant[e] : 0;
+    boxes = a.terrain + (long)v * a.B;
+    nbox = a.B;
+  }
+  Physics<HAS_DR> ph(m, em, s);
+  Solver sol(m, s);
+  const int nsub = MODE == MODE_STEP ? cfg->n_substeps : 1;
+  const float dt = m->timestep;
+  for (int sub = 0; sub < nsub; sub++) {
+    ph.position_stage();
+    ph.velocity_stage();
+    ph.constraint_stage(boxes, nbox, a.buf.box_friction, N, e);
+    sol.solve();
+    if (sub == nsub - 1) {
+      // ---- sensors of the last forward (pre-integration state), written as the "frame"
+      float* __restrict__ Fr = a.buf.frame;
+      V3 w = s.cvel[0].a, vl = s.cvel[0].l;
+      V3 dif = s.imu - s.com;
+      V3 gyro = mtmul(s.R0, w);
+      V3 glin = vl - cross(dif, w);
+      V3 llin = mtmul(s.R0, glin);
+      S6 cacc{v3(0, 0, 0), v3(-m->gravity[0], -m->gravity[1], -m->gravity[2])};
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        cacc = cacc + s.cddr[k] * s.qvel[3 + k] + s.cdr[k] * s.qacc[3 + k];
+      }
+      cacc.l = cacc.l + v3(s.qacc[0], s.qacc[1], s.qacc[2]);
+      V3 acc = mtmul(s.R0, cacc.l - cross(dif, cacc.a)) + cross(gyro, llin);
+      float fr[PGTT_NFRAME];
+      fr[PGTT_F_GYRO] = gyro.x; fr[PGTT_F_GYRO + 1] = gyro.y; fr[PGTT_F_GYRO + 2] = gyro.z;
+      fr[PGTT_F_ACCEL] = acc.x; fr[PGTT_F_ACCEL + 1] = acc.y; fr[PGTT_F_ACCEL + 2] = acc.z;
+      fr[PGTT_F_GLOBAL_LINVEL] = glin.x; fr[PGTT_F_GLOBAL_LINVEL + 1] = glin.y; fr[PGTT_F_GLOBAL_LINVEL + 2] = glin.z;
+      fr[PGTT_F_GLOBAL_ANGVEL] = w.x; fr[PGTT_F_GLOBAL_ANGVEL + 1] = w.y; fr[PGTT_F_GLOBAL_ANGVEL + 2] = w.z;
+      fr[PGTT_F_LOCAL_LINVEL] = llin.x; fr[PGTT_F_LOCAL_LINVEL + 1] = llin.y; fr[PGTT_F_LOCAL_LINVEL + 2] = llin.z;
+      fr[PGTT_F_UPVECTOR] = s.R0.m[2]; fr[PGTT_F_UPVECTOR + 1] = s.R0.m[5]; fr[PGTT_F_UPVECTOR + 2] = s.R0.m[8];
+      fr[PGTT_F_GRAVITY] = -s.R0.m[6]; fr[PGTT_F_GRAVITY + 1] = -s.R0.m[7]; fr[PGTT_F_GRAVITY + 2] = -s.R0.m[8];
+#pragma unroll
+      for (int f = 0; f < 4; f++) {
+        const int l = f ^ 1;                              // FR,FL,RR,RL -> legs 1,0,3,2
+        V3 p = mtmul(s.R0, s.sitef[l] - s.imu);
+        fr[PGTT_F_FEET_POS + 3 * f] = p.x; fr[PGTT_F_FEET_POS + 3 * f + 1] = p.y; fr[PGTT_F_FEET_POS + 3 * f + 2] = p.z;
+        S6 cv = s.cvel[3 + 3 * l];
+        V3 fv = cv.l - cross(s.sitef[l] - s.com, cv.a);
+        fr[PGTT_F_FEET_VEL + 3 * f] = fv.x; fr[PGTT_F_FEET_VEL + 3 * f + 1] = fv.y; fr[PGTT_F_FEET_VEL + 3 * f + 2] = fv.z;
+        bool touching = false;
+#pragma unroll
+        for (int c = 0; c < 8; c++) touching = touching || (s.con[c].leg == l && s.con[c].box != -2 && s.con[c].dist < 0.f);
+        fr[PGTT_F_CONTACT + f] = touching ? 1.0f : 0.0f;
+        fr[PGTT_F_FOOT_SITE_Z + f] = s.sitef[l].z;
+      }
+#pragma unroll
+      for (int i = 0; i < 12; i++) fr[PGTT_F_ACT_FORCE + i] = s.act_force[i];
+#pragma unroll
+      for (int i = 0; i < PGTT_NFRAME; i++) Fr[i * (long)N + e] = fr[i];
+      if (a.buf.dbg_contact) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) { a.buf.dbg_contact[((long)e * 8 + c) * 2] = s.con[c].leg; a.buf.dbg_contact[((long)e * 8 + c) * 2 + 1] = s.con[c].box; }
+      }
+      if (a.buf.dbg_dist) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) a.buf.dbg_dist[(long)e * 8 + c] = s.con[c].dist;
+      }
+    }
+    if (MODE == MODE_STEP) {
+      // ---- semi-implicit Euler (eulerdamp disabled)
+#pragma unroll
+      for (int i = 0; i < 18; i++) s.qvel[i] = s.qvel[i] + s.qacc[i] * dt;
+#pragma unroll
+      for (int i = 0; i < 3; i++) s.qpos[i] = s.qpos[i] + dt * s.qvel[i];
+      V3 wv = v3(s.qvel[3], s.qvel[4], s.qvel[5]);
+      float nn = normalize3(wv);
+      float sn, cs; sincosf(0.5f * (dt * nn), &sn, &cs);
+      Q4 q{s.qpos[3], s.qpos[4], s.qpos[5], s.qpos[6]};
+      Q4 q2 = qmul(q, Q4{cs, wv.x * sn, wv.y * sn, wv.z * sn});
+      normalize4(q2);
+      s.qpos[3] = q2.w; s.qpos[4] = q2.x; s.qpos[5] = q2.y; s.qpos[6] = q2.z;
+#pragma unroll
+      for (int j = 0; j < 12; j++) s.qpos[7 + j] = s.qpos[7 + j] + dt * s.qvel[6 + j];
+    }
+  }
+  if (MODE == MODE_STEP || a.write_qpos) {
+#pragma unroll
+    for (int i = 0; i < 19; i++) S[(PGTT_S_QPOS + i) * (long)N + e] = s.qpos[i];
+  }
+  if (MODE == MODE_STEP) {
+#pragma unroll
+    for (int i = 0; i < 18; i++) S[(PGTT_S_QVEL + i) * (long)N + e] = s.qvel[i];
+#pragma unroll
+    for (int i = 0; i < 12; i++) S[(PGTT_S_MOTOR_TARGETS + i) * (long)N + e] = s.ctrl[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 18; i++) S[(PGTT_S_QWARM + i) * (long)N + e] = s.warm[i];
+}
+
+// ------------------------------------------------------------------ reset: pose sampling (go2/joystick_pgtt.py:51-70)
+template <int UNUSED>
+__global__ __launch_bounds__(64) void reset_pose_kernel(KArgs a) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  const int N = a.N;
+  if (e >= N) return;
+  if (a.mask && !a.mask[e]) return;
+  const PgttModel* __restrict__ m = a.model;
+  float* __restrict__ S = a.buf.state;
+  const unsigned id = (unsigned)(a.env_off + e);
+  const unsigned ep = (unsigned)a.buf.istate[PGTT_I_RNG_CTR * (long)N + e];
+  float qpos[19];
+#pragma unroll
+  for (int i = 0; i < 19; i++) qpos[i] = m->key_qpos[i];
+  qpos[0] += rng_uniform(a.seed, id, ep, PGTT_RS_RESET_XY, 0) * 1.0f + -0.5f;
+  qpos[1] += rng_uniform(a.seed, id, ep, PGTT_RS_RESET_XY, 1) * 1.0f + -0.5f;
+  float yaw = rng_uniform(a.seed, id, ep, PGTT_RS_RESET_YAW, 0) * 6.28f + -3.14f;
+  float sn, cs; sincosf(0.5f * yaw, &sn, &cs);
+  Q4 q = qmul(Q4{qpos[3], qpos[4], qpos[5], qpos[6]}, Q4{cs, 0.f * sn, 0.f * sn, 1.f * sn});
+  qpos[3] = q.w; qpos[4] = q.x; qpos[5] = q.y; qpos[6] = q.z;
+#pragma unroll
+  for (int i = 0; i < 19; i++) S[(PGTT_S_QPOS + i) * (long)N + e] = qpos[i];
+#pragma unroll
+  for (int i = 0; i < 18; i++) {
+    S[(PGTT_S_QVEL + i) * (long)N + e] = i < 6 ? rng_uniform(a.seed, id, ep, PGTT_RS_RESET_VEL, i) * 0.2f + -0.1f : 0.f;
+    S[(PGTT_S_QWARM + i) * (long)N + e] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------ observe: one env per wave
+enum { OBS_STEP = 0, OBS_SCAN_LIFT = 1, OBS_RESET = 2, OBS_SCAN_ONLY = 3 };
+
+PG_INL float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+PG_INL float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// vertical ray (0,0,-1) from world point p against one terrain box; generic mjx _ray_box in the box frame
+PG_INL float ray_box_down(const TerrainBox& tb, V3 p) {
+  V3 rel = p - v3(tb.px, tb.py, tb.pz);
+  float lp[3] = {tb.m00 * rel.x + tb.m10 * rel.y + tb.m20 * rel.z, tb.m01 * rel.x + tb.m11 * rel.y + tb.m21 * rel.z,
+                 tb.m02 * rel.x + tb.m12 * rel.y + tb.m22 * rel.z};
+  float lv[3] = {-tb.m20, -tb.m21, -tb.m22};
+  float sz[3] = {tb.sx, tb.sy, tb.sz};
+  float best = INFINITY;
+#pragma unroll
+  for (int f = 0; f < 6; f++) {
+    const int ax = f % 3, i0 = ax == 0 ? 1 : 0, i1 = ax == 2 ? 1 : 2;
+    float side = f < 3 ? sz[ax] : -sz[ax];
+    float x = (side - lp[ax]) / lv[ax];
+    float p0 = lp[i0] + x * lv[i0], p1 = lp[i1] + x * lv[i1];
+    bool valid = (fabsf(p0) <= sz[i0]) && (fabsf(p1) <= sz[i1]) && (x >= 0.f);
+    best = (valid && x < best) ? x : best;
+  }
+  return best;
+}
+
+PG_INL float cubic_hermite(float t, float p0, float p1, float m0, float m1) {
+  float t2 = t * t, t3 = t2 * t;
+  return (2 * t3 - 3 * t2 + 1) * p0 + (t3 - 2 * t2 + t) * m0 + (-2 * t3 + 3 * t2) * p1 + (t3 - t2) * m1;
+}
+PG_INL float gait_get_z(float phi, float swing_height, float swing_min) {
+  const float T_swing = (float)(2 * M_PI * (1 - 0.5) / 2), T_peak = (float)(2 * M_PI * (1 + 0.5) / 2), T_stance = (float)(2 * M_PI * 0.5);
+  if (phi <= T_stance) return swing_min;
+  if (phi <= T_peak) return cubic_hermite((phi - T_stance) / T_swing, swing_min, swing_height, T_swing * 0.f, T_swing * 0.f);
+  return cubic_hermite((phi - T_peak) / T_swing, swing_height, swing_min, T_swing * 0.f, T_swing * 0.f);
+}
+
+template <int OMODE, bool HAS_TERRAIN>
+__global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __restrict__ action) {
+  const int e = blockIdx.x, lane = threadIdx.x, N = a.N;
+  if (OMODE != OBS_STEP && a.mask && !a.mask[e]) return;
+  const PgttModel* __restrict__ m = a.model;
+  const PgttConfig* __restrict__ cfg = a.cfg;
+  float* __restrict__ S = a.buf.state;
+  int* __restrict__ I = a.buf.istate;
+
+  __shared__ float sh_st[PGTT_NSTATE];
+  __shared__ float sh_fr[PGTT_NFRAME];
+  __shared__ float sh_scan[128];
+  __shared__ float sh_obs[PGTT_OBS + PGTT_PRIV + 2];
+  __shared__ float sh_act[12];
+
+  for (int r = lane; r < PGTT_NSTATE; r += 64) sh_st[r] = S[r * (long)N + e];
+  for (int r = lane; r < PGTT_NFRAME; r += 64) sh_fr[r] = a.buf.frame[r * (long)N + e];
+  if (OMODE == OBS_STEP && lane < 12) sh_act[lane] = action[(long)e * 12 + lane];
+  __syncthreads();
+
+  // ---------------- height scan (heightmap.py:25-67)
+  const float bx = sh_st[PGTT_S_QPOS + 0], by = sh_st[PGTT_S_QPOS + 1], bz = sh_st[PGTT_S_QPOS + 2];
+  float yaw;
+  if (OMODE == OBS_STEP || (OMODE == OBS_SCAN_ONLY && a.yaw_override != a.yaw_override)) {
+    float qw = sh_st[PGTT_S_QPOS + 3], qx = sh_st[PGTT_S_QPOS + 4], qy = sh_st[PGTT_S_QPOS + 5], qz = sh_st[PGTT_S_QPOS + 6];
+    float qn = sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+    qw /= qn; qx /= qn; qy /= qn; qz /= qn;
+    yaw = atan2f(2.0f * (qw * qz + qx * qy), 1.0f - 2.0f * (qy * qy + qz * qz));
+  } else if (OMODE == OBS_SCAN_ONLY) {
+    yaw = a.yaw_override;
+  } else {
+    yaw = 0.f;
+  }
+  float sy, cy; sincosf(yaw, &sy, &cy);
+  const float oz = bz + cfg->scan_z_offset;
+  V3 org[2]; float hit[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    int idx = lane + 64 * h;
+    int ii = idx < PGTT_NSCAN ? idx : 0;
+    int r = ii / PGTT_SCAN_W, c = ii - r * PGTT_SCAN_W;
+    float ox = ((float)(PGTT_SCAN_H - 1) * 0.5f - (float)r) * cfg->scan_dist_x;
+    float oy = ((float)(PGTT_SCAN_W - 1) * 0.5f - (float)c) * cfg->scan_dist_y;
+    float wx = ox * cy + oy * (-sy), wy = ox * sy + oy * cy;
+    org[h] = v3(bx + wx, by + wy, oz);
+    if (r == (PGTT_SCAN_H - 1) / 2 && c == (PGTT_SCAN_W - 1) / 2) org[h] = v3(bx, by, oz);
+    // plane z=0 (normal +z): x = -pnt_z / vec_z = pnt_z, valid if x >= 0
+    float x = oz;
+    hit[h] = x >= 0.f ? x : INFINITY;
+  }
+  if (HAS_TERRAIN) {
+    const int v = a.buf.variant ? a.buf.variant[e] : 0;
+    const TerrainBox* __restrict__ boxes = a.terrain + (long)v * a.B;
+    const float rf = sqrtf((0.5f * (PGTT_SCAN_H - 1) * cfg->scan_dist_x) * (0.5f * (PGTT_SCAN_H - 1) * cfg->scan_dist_x) +
+                           (0.5f * (PGTT_SCAN_W - 1) * cfg->scan_dist_y) * (0.5f * (PGTT_SCAN_W - 1) * cfg->scan_dist_y)) + 1e-3f;
+    for (int b = 0; b < a.B; b++) {
+      const float4 A = reinterpret_cast<const float4*>(boxes + b)[0];
+      float dx = A.x - bx, dy = A.y - by, rr = A.w + rf;
+      if (dx * dx + dy * dy > rr * rr) continue;            // wave-uniform cull: box cannot reach the footprint
+      TerrainBox tb = boxes[b];
+#pragma unroll
+      for (int h = 0; h < 2; h++) hit[h] = fminf(hit[h], ray_box_down(tb, org[h]));
+    }
+  }
+  float z[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    float dist = hit[h] == INFINITY ? -1.0f : hit[h];
+    z[h] = org[h].z + (-1.0f) * dist;
+    int idx = lane + 64 * h;
+    if (idx < PGTT_NSCAN) { sh_scan[idx] = z[h]; a.buf.scan_z[(long)e * PGTT_NSCAN + idx] = z[h]; }
+  }
+  if (OMODE == OBS_SCAN_ONLY) return;
+  const bool v1 = lane + 64 < PGTT_NSCAN;
+  if (OMODE == OBS_SCAN_LIFT) {
+    float zmax = wave_max(fmaxf(z[0], v1 ? z[1] : -INFINITY));
+    if (lane == 0) S[(PGTT_S_QPOS + 2) * (long)N + e] = bz + zmax;
+    return;
+  }
+  // ---------------- quadrant statistics (joystick_pgtt.py:169-190): n = 6 on both axes of the 13x9 grid
+  float qmax[4], qmin[4];
+  {
+    const int n = (PGTT_SCAN_H - 1) / 2;
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      int idx = lane + 64 * h;
+      if (idx >= PGTT_NSCAN) continue;
+      int r = idx / PGTT_SCAN_W, c = idx - r * PGTT_SCAN_W;
+      bool top = r < n, back = r >= n + 1, left = c < n, right = c >= n + 1;
+      int qd = (top && right) ? 0 : ((top && left) ? 1 : ((back && right) ? 2 : ((back && left) ? 3 : -1)));
+#pragma unroll
+      for (int k = 0; k < 4; k++) if (qd == k) { mx[k] = fmaxf(mx[k], z[h]); mn[k] = fminf(mn[k], z[h]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { qmax[k] = wave_max(mx[k]); qmin[k] = wave_min(mn[k]); }
+  }
+  const float zmin = wave_min(fminf(z[0], v1 ? z[1] : INFINITY));
+
+  // ---------------- per-env scalars (computed redundantly by every lane from LDS)
+  const unsigned id = (unsigned)(a.env_off + e);
+  const unsigned ep = (unsigned)I[PGTT_I_RNG_CTR * (long)N + e];
+  int step_ctr = I[PGTT_I_STEP * (long)N + e];
+  int timer = I[PGTT_I_STEPS_UNTIL_CMD * (long)N + e];
+  int ep_steps = I[PGTT_I_EP_STEPS * (long)N + e];
+  const float dt = cfg->ctrl_dt;
+  float cmd[3], phase[4], air[4], peak[4], hmax[4], hmin[4], last_contact[4], contact[4], first_contact[4];
+  float gait_freq, phase_dt;
+  bool prev_done = false;
+  if (OMODE == OBS_RESET) {
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+      cmd[i] = rng_uniform(a.seed, id, ep, PGTT_RS_RESET_CMD, i) * (cfg->cmd_u_max[i] - cfg->cmd_u_min[i]) + cfg->cmd_u_min[i];
+    gait_freq = rng_uniform(a.seed, id, ep, PGTT_RS_RESET_FREQ, 0) * (cfg->gait_freq[1] - cfg->gait_freq[0]) + cfg->gait_freq[0];
+    phase_dt = (float)(2 * M_PI) * dt * gait_freq;
+    phase[0] = 0.f; phase[1] = (float)M_PI; phase[2] = (float)M_PI; phase[3] = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; f++) { air[f] = 0.f; peak[f] = 0.f; hmax[f] = 0.1f; hmin[f] = 0.f; last_contact[f] = 0.f; contact[f] = 0.f; first_contact[f] = 0.f; }
+    timer = exp_timer(a.seed, id, ep, PGTT_RS_RESET_TIMER, dt);
+    step_ctr = 0; ep_steps = 0;
+    __syncthreads();
+    // info arrays that _get_obs reads
+    if (lane < 12) { sh_st[PGTT_S_LAST_ACT + lane] = 0.f; sh_st[PGTT_S_LAST_LAST_ACT + lane] = 0.f; sh_st[PGTT_S_MOTOR_TARGETS + lane] = 0.f; }
+    if (lane < 24) { sh_st[PGTT_S_QERR_HIST + lane] = 0.f; sh_st[PGTT_S_QVEL_HIST + lane] = 0.f; }
+    __syncthreads();
+  } else {
+    prev_done = cfg->autoreset && a.buf.done[e] != 0.f;
+    if (prev_done) ep_steps = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) cmd[i] = sh_st[PGTT_S_CMD + i];
+    gait_freq = sh_st[PGTT_S_GAIT_FREQ]; phase_dt = sh_st[PGTT_S_PHASE_DT];
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+      phase[f] = sh_st[PGTT_S_PHASE + f];
+      last_contact[f] = sh_st[PGTT_S_LAST_CONTACT + f];
+      contact[f] = sh_fr[PGTT_F_CONTACT + f];
+      bool filt = (contact[f] != 0.f) || (last_contact[f] != 0.f);
+      first_contact[f] = (sh_st[PGTT_S_AIR_TIME + f] > 0.f ? 1.f : 0.f) * (filt ? 1.f : 0.f);
+      air[f] = sh_st[PGTT_S_AIR_TIME + f] + dt;
+      peak[f] = fmaxf(sh_st[PGTT_S_SWING_PEAK + f], sh_fr[PGTT_F_FEET_POS + 3 * f + 2]);
+      hmax[f] = qmax[f] - qmin[f]; hmin[f] = qmin[f];
+    }
+  }
+
+  // ---------------- observation rows in LDS (joystick_pgtt.py:336-365)
+  const float lvl = cfg->noise_level;
+  for (int i = lane; i < PGTT_OBS; i += 64) {
+    float v;
+    if (i < 3) v = sh_fr[PGTT_F_GYRO + i] + (2.f * rng_uniform(a.seed, id, ep, PGTT_RS_GYRO, i) - 1.f) * lvl * cfg->noise_gyro;
+    else if (i < 6) v = sh_fr[PGTT_F_GRAVITY + i - 3] + (2.f * rng_uniform(a.seed, id, ep, PGTT_RS_GRAVITY, i - 3) - 1.f) * lvl * cfg->noise_gravity;
+    else if (i < 18) v = (sh_st[PGTT_S_QPOS + 7 + i - 6] + (2.f * rng_uniform(a.seed, id, ep, PGTT_RS_QPOS, i - 6) - 1.f) * lvl * cfg->noise_joint_pos) - m->key_qpos[7 + i - 6];
+    else if (i < 30) v = sh_st[PGTT_S_QVEL + 6 + i - 18] + (2.f * rng_uniform(a.seed, id, ep, PGTT_RS_QVEL, i - 18) - 1.f) * lvl * cfg->noise_joint_vel;
+    else if (i < 34) v = cosf(sel4(i - 30, phase[0], phase[1], phase[2], phase[3]));
+    else if (i < 38) v = sinf(sel4(i - 34, phase[0], phase[1], phase[2], phase[3]));
+    else if (i < 38 + PGTT_NSCAN) v = (sh_scan[i - 38] - zmin) + (2.f * rng_uniform(a.seed, id, ep, PGTT_RS_SCAN, i - 38) - 1.f) * lvl * cfg->noise_heightscan;
+    else if (i == 38 + PGTT_NSCAN) v = gait_freq;
+    else if (i < 39 + PGTT_NSCAN + 12) v = sh_st[PGTT_S_LAST_ACT + i - (39 + PGTT_NSCAN)];
+    else v = sel4(i - (51 + PGTT_NSCAN), cmd[0], cmd[1], cmd[2], 0.f);
+    sh_obs[i] = v;
+  }
+  if (lane < PGTT_PRIV - PGTT_OBS) {
+    int i = lane; float v;
+    if (i < 3) v = sh_fr[PGTT_F_LOCAL_LINVEL + i];
+    else if (i < 6) v = sh_fr[PGTT_F_ACCEL + i - 3];
+    else if (i < 9) v = sh_fr[PGTT_F_GLOBAL_ANGVEL + i - 6];
+    else if (i < 21) v = sh_fr[PGTT_F_ACT_FORCE + i - 9];
+    else if (i < 25) v = sel4(i - 21, last_contact[0], last_contact[1], last_contact[2], last_contact[3]);
+    else if (i < 37) v = sh_fr[PGTT_F_FEET_VEL + i - 25];
+    else if (i < 41) v = sel4(i - 37, air[0], air[1], air[2], air[3]);
+    else v = 0.f;
+    sh_obs[PGTT_OBS + PGTT_OBS + i] = v;
+  }
+  // history buffers (joystick_pgtt.py:319-334): motor_targets in sh_st was written by the physics kernel
+  float hist_q = 0.f, hist_v = 0.f; const bool upd = (step_ctr % cfg->history_update_steps) == 0;
+  if (lane < 24) {
+    if (upd) {
+      hist_v = lane < 12 ? sh_st[PGTT_S_QVEL + 6 + lane] : sh_st[PGTT_S_QVEL_HIST + lane - 12];
+      hist_q = lane < 12 ? sh_st[PGTT_S_QPOS + 7 + lane] - sh_st[PGTT_S_MOTOR_TARGETS + lane] : sh_st[PGTT_S_QERR_HIST + lane - 12];
+    } else { hist_v = sh_st[PGTT_S_QVEL_HIST + lane]; hist_q = sh_st[PGTT_S_QERR_HIST + lane]; }
+  }
+  __syncthreads();
+  for (int i = lane; i < PGTT_OBS; i += 64) sh_obs[PGTT_OBS + i] = sh_obs[i];     // privileged = state || extras
+  __syncthreads();
+
+  // ---------------- rewards, termination, bookkeeping
+  float reward = 0.f; bool done = false; float metrics[PGTT_NMETRIC];
+#pragma unroll
+  for (int k = 0; k < PGTT_NMETRIC; k++) metrics[k] = 0.f;
+  float act_i = 0.f;
+  if (OMODE == OBS_STEP) {
+    done = sh_fr[PGTT_F_UPVECTOR + 2] < 0.f;
+    float rew[PGTT_NREW];
+    const float cmd_norm = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1] + cmd[2] * cmd[2]);
+    {
+      float e0 = cmd[0] - sh_fr[PGTT_F_LOCAL_LINVEL], e1 = cmd[1] - sh_fr[PGTT_F_LOCAL_LINVEL + 1];
+      rew[PGTT_R_TRACKING_LIN_VEL] = expf(-(e0 * e0 + e1 * e1) / cfg->tracking_sigma);
+      float ea = cmd[2] - sh_fr[PGTT_F_GYRO + 2];
+      rew[PGTT_R_TRACKING_ANG_VEL] = expf(-(ea * ea) / cfg->tracking_sigma);
+    }
+    rew[PGTT_R_LIN_VEL_Z] = sh_fr[PGTT_F_GLOBAL_LINVEL + 2] * sh_fr[PGTT_F_GLOBAL_LINVEL + 2];
+    rew[PGTT_R_ANG_VEL_XY] = sh_fr[PGTT_F_GLOBAL_ANGVEL] * sh_fr[PGTT_F_GLOBAL_ANGVEL] + sh_fr[PGTT_F_GLOBAL_ANGVEL + 1] * sh_fr[PGTT_F_GLOBAL_ANGVEL + 1];
+    rew[PGTT_R_ORIENTATION] = sh_fr[PGTT_F_UPVECTOR] * sh_fr[PGTT_F_UPVECTOR] + sh_fr[PGTT_F_UPVECTOR + 1] * sh_fr[PGTT_F_UPVECTOR + 1];
+    {
+      float sa = 0.f, lim = 0.f, pose = 0.f, s2 = 0.f, s1 = 0.f, en = 0.f, ar = 0.f;
+#pragma unroll
+      for (int i = 0; i < 12; i++) {
+        float q = sh_st[PGTT_S_QPOS + 7 + i], dq = q - m->key_qpos[7 + i];
+        sa += fabsf(dq);
+        pose += (dq * dq) * ((i % 3) == 0 ? 1.0f : 0.1f);
+        float lo = m->jnt_range[i][0] * cfg->soft_joint_pos_limit_factor, hi = m->jnt_range[i][1] * cfg->soft_joint_pos_limit_factor;
+        lim += -fminf(q - lo, 0.f) + fmaxf(q - hi, 0.f);
+        float f = sh_fr[PGTT_F_ACT_FORCE + i];
+        s2 += f * f; s1 += fabsf(f);
+        en += fabsf(sh_st[PGTT_S_QVEL + 6 + i]) * fabsf(f);
+        float da = sh_act[i] - sh_st[PGTT_S_LAST_ACT + i]; ar += da * da;
+      }
+      rew[PGTT_R_STAND_STILL] = sa * (cmd_norm < 0.01f ? 1.f : 0.f);
+      rew[PGTT_R_POSE] = pose; rew[PGTT_R_DOF_POS_LIMITS] = lim;
+      rew[PGTT_R_TORQUES] = sqrtf(s2) + s1; rew[PGTT_R_ENERGY] = en; rew[PGTT_R_ACTION_RATE] = ar;
+    }
+    rew[PGTT_R_TERMINATION] = done ? 1.f : 0.f;
+    {
+      float slip = 0.f, clear = 0.f, perr = 0.f, swing = 0.f, airr = 0.f, con = 0.f, center = 0.f, fh = 0.f, minfoot = INFINITY;
+#pragma unroll
+      for (int f = 0; f < 4; f++) {
+        float vx = sh_fr[PGTT_F_FEET_VEL + 3 * f], vy = sh_fr[PGTT_F_FEET_VEL + 3 * f + 1];
+        float v2 = vx * vx + vy * vy;
+        slip += v2 * contact[f];
+        float px = sh_fr[PGTT_F_FEET_POS + 3 * f], py = sh_fr[PGTT_F_FEET_POS + 3 * f + 1], pz = sh_fr[PGTT_F_FEET_POS + 3 * f + 2];
+        clear += fabsf(pz - (hmax[f] + cfg->swing_height)) * sqrtf(sqrtf(v2));
+        float rz = gait_get_z(phase[f], hmax[f] + cfg->swing_height, cfg->base_feet_distance);
+        perr += (pz - rz) * (pz - rz);
+        bool swing_mask = phase[f] / (float)(2 * M_PI) >= 0.5f;
+        swing += ((pz - cfg->swing_height) * (pz - cfg->swing_height)) * (swing_mask ? 1.f : 0.f);
+        con += (swing_mask && contact[f] != 0.f) ? 1.f : 0.f;
+        airr += (air[f] - 0.1f) * first_contact[f];
+        center += px * px + py * py;
+        float er = peak[f] / cfg->swing_height - 1.0f;
+        fh += (er * er) * first_contact[f];
+        minfoot = fminf(minfoot, sh_fr[PGTT_F_FOOT_SITE_Z + f]);
+      }
+      float moving = cmd_norm > 0.01f ? 1.f : 0.f;
+      rew[PGTT_R_FEET_SLIP] = slip * moving; rew[PGTT_R_FEET_CLEARANCE] = clear;
+      rew[PGTT_R_FEET_PHASE] = expf(-perr / cfg->phase_sigma); rew[PGTT_R_FEET_SWING] = swing;
+      rew[PGTT_R_FEET_AIR_TIME] = airr * moving; rew[PGTT_R_CONTACT] = -con; rew[PGTT_R_CENTER] = center;
+      rew[PGTT_R_FEET_HEIGHT] = fh * moving;
+      float bh = sh_st[PGTT_S_QPOS + 2] - minfoot - 0.27f;
+      rew[PGTT_R_BODY_HEIGHT] = bh * bh;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < PGTT_NREW; k++) { metrics[k] = rew[k] * cfg->reward_scale[k]; sum += metrics[k]; }
+    reward = fminf(fmaxf(sum * dt, 0.f), 10000.f);
+    // bookkeeping (joystick_pgtt.py:205-227)
+    step_ctr += 1;
+#pragma unroll
+    for (int f = 0; f < 4; f++) phase[f] = fmodf(phase[f] + phase_dt, (float)(2 * M_PI));
+    timer -= 1;
+    if (timer <= 0) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        float y = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_Y, i) * (cfg->cmd_u_max[i] - cfg->cmd_u_min[i]) + cfg->cmd_u_min[i];
+        float zb = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_Z, i) < cfg->cmd_b[i] ? 1.f : 0.f;
+        float wb = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_W, i) < 0.5f ? 1.f : 0.f;
+        cmd[i] = cmd[i] - wb * (cmd[i] - y * zb);
+      }
+    }
+    if (done || timer <= 0) timer = exp_timer(a.seed, id, ep, PGTT_RS_TIMER, dt);
+    float sp = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+      float nc = contact[f] != 0.f ? 0.f : 1.f;
+      air[f] *= nc; peak[f] *= nc; last_contact[f] = contact[f]; sp += peak[f];
+    }
+    metrics[PGTT_NREW] = sp / 4;
+    if (lane < 12) act_i = sh_act[lane];
+  }
+  // ---------------- Episode / AutoReset wrapper semantics (UPSTREAM-RECALL)
+  bool wdone = done;
+  if (OMODE == OBS_STEP && cfg->autoreset) {
+    ep_steps += 1;
+    if (ep_steps >= cfg->episode_length) wdone = true;
+    if (a.buf.ep_metrics) {
+      const float keep = prev_done ? 0.f : 1.f;
+      for (int k = lane; k < PGTT_NMETRIC + 2; k += 64) {
+        float add = k < PGTT_NMETRIC ? 0.f : (k == PGTT_NMETRIC ? reward : 1.0f);
+#pragma unroll
+        for (int j = 0; j < PGTT_NMETRIC; j++) if (j == k) add = metrics[j];
+        float* p = a.buf.ep_metrics + k * (long)N + e;
+        *p = (*p + add) * keep;
+      }
+    }
+  }
+
+  // ---------------- stores
+  if (lane < 3) S[(PGTT_S_CMD + lane) * (long)N + e] = sel4(lane, cmd[0], cmd[1], cmd[2], 0.f);
+  if (lane < 4) {
+    S[(PGTT_S_PHASE + lane) * (long)N + e] = sel4(lane, phase[0], phase[1], phase[2], phase[3]);
+    S[(PGTT_S_AIR_TIME + lane) * (long)N + e] = sel4(lane, air[0], air[1], air[2], air[3]);
+    S[(PGTT_S_SWING_PEAK + lane) * (long)N + e] = sel4(lane, peak[0], peak[1], peak[2], peak[3]);
+    S[(PGTT_S_HMAX + lane) * (long)N + e] = sel4(lane, hmax[0], hmax[1], hmax[2], hmax[3]);
+    S[(PGTT_S_HMIN + lane) * (long)N + e] = sel4(lane, hmin[0], hmin[1], hmin[2], hmin[3]);
+    S[(PGTT_S_LAST_CONTACT + lane) * (long)N + e] = sel4(lane, last_contact[0], last_contact[1], last_contact[2], last_contact[3]);
+  }
+  if (lane < 24) { S[(PGTT_S_QVEL_HIST + lane) * (long)N + e] = hist_v; S[(PGTT_S_QERR_HIST + lane) * (long)N + e] = hist_q; }
+  if (lane < 12) {
+    if (OMODE == OBS_STEP) {
+      S[(PGTT_S_LAST_LAST_ACT + lane) * (long)N + e] = sh_st[PGTT_S_LAST_ACT + lane];
+      S[(PGTT_S_LAST_ACT + lane) * (long)N + e] = act_i;
+    } else {
+      S[(PGTT_S_LAST_LAST_ACT + lane) * (long)N + e] = 0.f; S[(PGTT_S_LAST_ACT + lane) * (long)N + e] = 0.f;
+      S[(PGTT_S_MOTOR_TARGETS + lane) * (long)N + e] = 0.f;
+    }
+  }
+  if (lane == 0) {
+    S[PGTT_S_PHASE_DT * (long)N + e] = phase_dt; S[PGTT_S_GAIT_FREQ * (long)N + e] = gait_freq;
+    I[PGTT_I_STEP * (long)N + e] = step_ctr; I[PGTT_I_STEPS_UNTIL_CMD * (long)N + e] = timer;
+    I[PGTT_I_RNG_CTR * (long)N + e] = (int)(ep + 1u); I[PGTT_I_EP_STEPS * (long)N + e] = ep_steps;
+    a.buf.reward[e] = reward; a.buf.done[e] = wdone ? 1.f : 0.f;
+  }
+  for (int k = lane; k < PGTT_NMETRIC; k += 64) {
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < PGTT_NMETRIC; j++) if (j == k) v = metrics[j];
+    a.buf.metrics[k * (long)N + e] = v;
+  }
+  const bool restore = OMODE == OBS_STEP && cfg->autoreset && wdone && a.buf.first_state && a.buf.first_obs;
+  if (restore) {
+    for (int r = lane; r < PGTT_S_CMD; r += 64) S[r * (long)N + e] = a.buf.first_state[r * (long)N + e];
+    const float* fo = a.buf.first_obs + (long)e * (PGTT_OBS + PGTT_PRIV);
+    for (int i = lane; i < PGTT_OBS; i += 64) a.buf.obs_state[(long)e * PGTT_OBS + i] = fo[i];
+    for (int i = lane; i < PGTT_PRIV; i += 64) a.buf.obs_priv[(long)e * PGTT_PRIV + i] = fo[PGTT_OBS + i];
+  } else {
+    for (int i = lane; i < PGTT_OBS; i += 64) a.buf.obs_state[(long)e * PGTT_OBS + i] = sh_obs[i];
+    for (int i = lane; i < PGTT_PRIV; i += 64) a.buf.obs_priv[(long)e * PGTT_PRIV + i] = sh_obs[PGTT_OBS + i];
+  }
+  if (OMODE == OBS_RESET) {
+    if (a.buf.first_state) for (int r = lane; r < PGTT_S_CMD; r += 64) a.buf.first_state[r * (long)N + e] = sh_st[r];
+    if (a.buf.first_obs) for (int i = lane; i < PGTT_OBS + PGTT_PRIV; i += 64) a.buf.first_obs[(long)e * (PGTT_OBS + PGTT_PRIV) + i] = sh_obs[i];
+    if (a.buf.ep_metrics) for (int k = lane; k < PGTT_NMETRIC + 2; k += 64) a.buf.ep_metrics[k * (long)N + e] = 0.f;
+  }
+}
+
+}  // namespace pgtt

@@ -1,0 +1,154 @@
+"""Host-side mirror of the reference env interface (go2/joystick_pgtt.py:35-48, go2/base.py:216-231):
+
+    env = Joystick(task="stairs", config=training_config(), num_envs=4096, terrain=level4, device="cuda:0")
+    obs = env.reset(seed)                 # {'state': [N,171], 'privileged_state': [N,215]} torch tensors
+    obs, reward, done, info = env.step(action)   # action [N,12] in [-1,1], FR,FL,RR,RL order
+
+The reference env is functional (State pytrees under jax.vmap); this one is the batched, stateful
+equivalent: state lives in caller-visible torch tensors (SoA in HBM) and every call enqueues HIP
+kernels of libpgtt.so on the current torch stream.  PyTorch is only the allocator / stream provider.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Dict, Optional
+
+import numpy as np
+import torch
+
+from . import abi, configs, mjcf, native
+
+
+class Joystick:
+    """Batched PGTT joystick env on one GPU.  Properties mirror reference go2/base.py:216-231."""
+
+    def __init__(self, task: str = "flat_terrain", config: Optional[Dict[str, Any]] = None, num_envs: int = 4096,
+                 terrain: Optional[np.ndarray] = None, device: str = "cuda:0", params: Optional[torch.Tensor] = None,
+                 variant: Optional[torch.Tensor] = None, box_friction: Optional[torch.Tensor] = None,
+                 autoreset: bool = False, debug_contacts: bool = False, env_id_offset: int = 0,
+                 model: Optional[Dict[str, Any]] = None):
+        self._config = dict(configs.default_config() if config is None else config)
+        self._config["autoreset"] = int(autoreset)
+        self.task = task
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise native.PgttError("Joystick needs a ROCm device (device='cuda:N'); there is no CPU path")
+        self._model = mjcf.load_model(task) if model is None else model
+        self._ms = abi.model_struct(self._model)
+        self._cs = abi.config_struct(self._config)
+        self._lib = native.lib()
+        self._h = C.c_void_p()
+        native.check(self._lib.pgtt_create(C.byref(self._cs), C.byref(self._ms), self.device.index or 0,
+                                           self.num_envs, C.byref(self._h)))
+        self.env_id_offset = int(env_id_offset)
+        self.terrain = None
+        if task == "stairs":
+            if terrain is None:
+                raise ValueError("task='stairs' needs a terrain table (T,B,10), e.g. assets/terrains/level4.npy")
+            self.set_terrain(terrain)
+        n = self.num_envs
+        self.buffers: Dict[str, torch.Tensor] = {}
+        for spec in abi.BUFFER_SPECS:
+            dt = torch.float32 if spec[2] == np.float32 else torch.int32
+            self.buffers[spec[0]] = torch.zeros(abi.buffer_shape(spec, n), dtype=dt, device=self.device)
+        if params is not None:
+            self.buffers["params"] = params.to(self.device, torch.float32).contiguous()
+            assert self.buffers["params"].shape == (abi.NPARAM, n)
+        if variant is not None:
+            self.buffers["variant"] = variant.to(self.device, torch.int32).contiguous()
+        if box_friction is not None:
+            self.buffers["box_friction"] = box_friction.to(self.device, torch.float32).contiguous()
+            assert self.buffers["box_friction"].shape == (abi.MAX_BOX, n)
+        if debug_contacts:
+            self.buffers["dbg_contact"] = torch.zeros((n, abi.NCON * 2), dtype=torch.int32, device=self.device)
+            self.buffers["dbg_dist"] = torch.zeros((n, abi.NCON), dtype=torch.float32, device=self.device)
+        self._bind()
+        self._seed = 0
+
+    # ---- reference-compatible properties
+    @property
+    def dt(self) -> float:
+        return self._config["ctrl_dt"]
+
+    @property
+    def action_size(self) -> int:
+        return abi.NU
+
+    @property
+    def observation_size(self) -> Dict[str, int]:
+        return {"state": abi.OBS, "privileged_state": abi.PRIV}
+
+    @property
+    def config(self) -> Dict[str, Any]:
+        return self._config
+
+    @property
+    def model(self) -> Dict[str, Any]:
+        return self._model
+
+    def _bind(self) -> None:
+        b = abi.PgttBuffers()
+        for name, _ in abi.PgttBuffers._fields_:
+            t = self.buffers.get(name)
+            setattr(b, name, None if t is None else t.data_ptr())
+        native.check(self._lib.pgtt_bind(self._h, C.byref(b)))
+
+    def set_terrain(self, terrain: np.ndarray) -> None:
+        t = np.ascontiguousarray(terrain, dtype=np.float32)
+        assert t.ndim == 3 and t.shape[2] == 10 and t.shape[1] <= abi.MAX_BOX
+        native.check(self._lib.pgtt_set_terrain(self._h, t.ctypes.data, t.shape[0], t.shape[1]))
+        self.terrain = t
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _obs(self) -> Dict[str, torch.Tensor]:
+        return {"state": self.buffers["obs_state"], "privileged_state": self.buffers["obs_priv"]}
+
+    def reset(self, seed: int = 0, mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        self._seed = int(seed)
+        mp = None
+        if mask is not None:
+            mask = mask.to(self.device, torch.uint8).contiguous()
+            mp = mask.data_ptr()
+        native.check(self._lib.pgtt_reset(self._h, self._seed, self.env_id_offset, mp, self._stream()))
+        return self._obs()
+
+    def step(self, action: torch.Tensor):
+        a = action.to(self.device, torch.float32).contiguous()
+        assert a.shape == (self.num_envs, abi.NU)
+        native.check(self._lib.pgtt_step(self._h, a.data_ptr(), self._stream()))
+        info = {"metrics": self.buffers["metrics"], "episode_metrics": self.buffers["ep_metrics"]}
+        return self._obs(), self.buffers["reward"], self.buffers["done"], info
+
+    def physics(self, action: torch.Tensor) -> None:
+        a = action.to(self.device, torch.float32).contiguous()
+        native.check(self._lib.pgtt_physics(self._h, a.data_ptr(), self._stream()))
+
+    def observe(self, action: torch.Tensor) -> None:
+        a = action.to(self.device, torch.float32).contiguous()
+        native.check(self._lib.pgtt_observe(self._h, a.data_ptr(), self._stream()))
+
+    def scan(self, yaw: Optional[float] = None) -> torch.Tensor:
+        native.check(self._lib.pgtt_scan(self._h, float("nan") if yaw is None else float(yaw), self._stream()))
+        return self.buffers["scan_z"]
+
+    def enable_timing(self, on: bool = True) -> None:
+        native.check(self._lib.pgtt_enable_timing(self._h, int(on)))
+
+    def last_kernel_ms(self):
+        p, o = C.c_float(), C.c_float()
+        native.check(self._lib.pgtt_last_kernel_ms(self._h, C.byref(p), C.byref(o)))
+        return p.value, o.value
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.pgtt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

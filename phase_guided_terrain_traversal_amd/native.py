@@ -1,0 +1,52 @@
+"""Loader for libpgtt.so (the HIP/gfx950 product library).  Fails loudly when the library is missing
+or when no GPU is usable — there is no CPU fallback anywhere in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpgtt.so")
+_LIB: Optional[C.CDLL] = None
+
+EXPORTS = ["pgtt_create", "pgtt_destroy", "pgtt_set_terrain", "pgtt_bind", "pgtt_reset", "pgtt_step",
+           "pgtt_physics", "pgtt_observe", "pgtt_scan", "pgtt_enable_timing", "pgtt_last_kernel_ms",
+           "pgtt_sizeof_model", "pgtt_sizeof_config", "pgtt_sizeof_buffers", "pgtt_version", "pgtt_last_error"]
+
+
+class PgttError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise PgttError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.pgtt_last_error.restype = C.c_char_p
+        L.pgtt_version.restype = C.c_char_p
+        L.pgtt_create.argtypes = [C.POINTER(abi.PgttConfig), C.POINTER(abi.PgttModel), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.pgtt_destroy.argtypes = [C.c_void_p]
+        L.pgtt_set_terrain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.pgtt_bind.argtypes = [C.c_void_p, C.POINTER(abi.PgttBuffers)]
+        L.pgtt_reset.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p]
+        for fn in ("pgtt_step", "pgtt_physics", "pgtt_observe"):
+            getattr(L, fn).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pgtt_scan.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
+        L.pgtt_enable_timing.argtypes = [C.c_void_p, C.c_int]
+        L.pgtt_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        assert L.pgtt_sizeof_model() == C.sizeof(abi.PgttModel)
+        assert L.pgtt_sizeof_config() == C.sizeof(abi.PgttConfig)
+        assert L.pgtt_sizeof_buffers() == C.sizeof(abi.PgttBuffers)
+        _LIB = L
+    return _LIB
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise PgttError(f"libpgtt error {rc}: {lib().pgtt_last_error().decode()}")
