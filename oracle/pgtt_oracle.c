@@ -293,7 +293,9 @@ typedef struct PgttOraclePostIn {
       RT obs[PGTT_OBS], priv[PGTT_PRIV];                                                                                 \
       task_reset_##SUF(&c, d, &in, obs, priv);                                                                           \
       scatter_##SUF(B, N, e, d, &in);                                                                                    \
-      int contact[4] = {0, 0, 0, 0};                                                                                     \
+      int contact[4]; static const int lofr[4] = {1, 0, 3, 2};                                                           \
+      for (int f = 0; f < 4; f++) { contact[f] = 0;                                                                      \
+        for (int cc = 0; cc < 8; cc++) if (d->contact[cc].foot == lofr[f] && d->contact[cc].box != -2 && d->contact[cc].dist < 0) contact[f] = 1; } \
       write_frame_##SUF(B, N, e, d, contact); write_dbg_##SUF(B, e, d);                                                  \
       for (int i = 0; i < PGTT_OBS; i++) B->obs_state[e*PGTT_OBS + i] = (float)obs[i];                                   \
       for (int i = 0; i < PGTT_PRIV; i++) B->obs_priv[e*PGTT_PRIV + i] = (float)priv[i];                                 \

@@ -11,6 +11,12 @@
 
 #include "pgtt_kernels.hip.h"
 
+// the eight physics_kernel instantiations live in their own translation units (pgtt_physics_inst.hip,
+// compiled in parallel); this file only sees their host launchers
+#define PG_DECL(M, D, T) void pgtt_launch_physics_##M##_##D##_##T(int nblocks, hipStream_t st, const pgtt::KArgs& a, const float* action);
+PG_DECL(0, 0, 0) PG_DECL(0, 0, 1) PG_DECL(0, 1, 0) PG_DECL(0, 1, 1) PG_DECL(1, 0, 0) PG_DECL(1, 0, 1) PG_DECL(1, 1, 0) PG_DECL(1, 1, 1)
+#undef PG_DECL
+
 namespace {
 
 thread_local std::string g_err;
@@ -51,12 +57,6 @@ pgtt::KArgs make_args(pgtt_env* h, const unsigned char* mask, float yaw_override
   a.buf = h->buf; a.N = h->N; a.seed = h->seed; a.env_off = h->env_off; a.mask = mask; a.yaw_override = yaw_override; a.write_qpos = 0;
   return a;
 }
-
-// the eight physics_kernel instantiations live in their own translation units (pgtt_physics_inst.hip,
-// compiled in parallel); this file only sees their host launchers
-#define PG_DECL(M, D, T) void pgtt_launch_physics_##M##_##D##_##T(int nblocks, hipStream_t st, const pgtt::KArgs& a, const float* action);
-PG_DECL(0, 0, 0) PG_DECL(0, 0, 1) PG_DECL(0, 1, 0) PG_DECL(0, 1, 1) PG_DECL(1, 0, 0) PG_DECL(1, 0, 1) PG_DECL(1, 1, 0) PG_DECL(1, 1, 1)
-#undef PG_DECL
 
 template <int MODE>
 void launch_physics(pgtt_env* h, const pgtt::KArgs& a, const float* action, hipStream_t st) {

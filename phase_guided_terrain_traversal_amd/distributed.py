@@ -1,0 +1,63 @@
+"""Multi-GPU layer: envs shard trivially (one process per GPU, contiguous global env-id ranges, terrain table
+and model replicated); the ONLY collective on the path is the all-reduce of the episodic return / metric sums
+(reference: Brax's Episode-wrapper metrics are `pmean`-ed across devices inside ppo.train — SURVEY 2.1, 5).
+
+`torch.distributed` backend "nccl" is RCCL on ROCm (xGMI inside a node); the message is 25 floats, i.e. pure
+latency, so it is issued as ONE fused buffer every `interval` steps, never per metric.  With backend "gloo" the
+same code runs on CPU tensors (used by the world_size-2 tests).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import abi
+
+
+def shard_range(num_envs_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous env-id range [lo, hi) of `rank`; the remainder goes to the lowest ranks."""
+    base, rem = divmod(int(num_envs_total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, local_rank, world) from the torchrun environment; initialises the process group when world > 1."""
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+    return rank, local, world
+
+
+class MetricReducer:
+    """Fused all-reduce of [22 metric sums, sum_reward, n_done, n_envs] (= 25 floats)."""
+
+    SIZE = abi.NMETRIC + 3
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.acc = torch.zeros(self.SIZE, dtype=torch.float32, device=device)
+
+    def accumulate(self, metrics: torch.Tensor, reward: torch.Tensor, done: torch.Tensor) -> None:
+        """metrics [22, N], reward [N], done [N] of one step (local shard)."""
+        self.acc[:abi.NMETRIC] += metrics.sum(dim=1)
+        self.acc[abi.NMETRIC] += reward.sum()
+        self.acc[abi.NMETRIC + 1] += done.sum()
+        self.acc[abi.NMETRIC + 2] += float(reward.shape[0])
+
+    def reduce(self) -> Dict[str, torch.Tensor]:
+        """Sum over ranks (one RCCL all-reduce), reset the local accumulator, return global means."""
+        buf = self.acc.clone()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        self.acc.zero_()
+        n = buf[abi.NMETRIC + 2].clamp(min=1.0)
+        return {"metrics_mean": buf[:abi.NMETRIC] / n, "reward_mean": buf[abi.NMETRIC] / n,
+                "done_count": buf[abi.NMETRIC + 1], "env_steps": buf[abi.NMETRIC + 2]}

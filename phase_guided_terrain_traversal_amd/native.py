@@ -27,6 +27,9 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise PgttError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        # torch ships its own HIP runtime: load it FIRST so that libpgtt.so binds to the same libamdhip64
+        # (loading /opt/rocm's copy first leaves torch with "No HIP GPUs are available")
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         L.pgtt_last_error.restype = C.c_char_p
         L.pgtt_version.restype = C.c_char_p
