@@ -56,6 +56,14 @@ def _vec(s: str, n: Optional[int] = None) -> np.ndarray:
     return v
 
 
+def _vec_d(s: str, default: str) -> np.ndarray:
+    """Partial attribute: the given leading values override MuJoCo's defaults, the tail keeps them."""
+    d = _vec(default)
+    v = _vec(s)
+    d[:v.size] = v[:d.size]
+    return d
+
+
 def _load_tree(path: str) -> ET.Element:
     """Parse an MJCF file, splicing <include file=.../> elements in place (MuJoCo semantics)."""
     root = ET.parse(path).getroot()
@@ -170,7 +178,8 @@ def compile_mjcf(path: str, sim_dt: float = 0.005, Kp: float = 40.0, Kd: float =
         a = elem_attrs(e, "geom", childclass, _GEOM_DEFAULTS)
         geoms.append(dict(name=a.get("name"), body=body_id, type=a["type"],
                           size=_vec(a.get("size", "0 0 0"), 3), pos=_vec(a["pos"]), quat=_vec(a["quat"]),
-                          friction=_vec(a["friction"], 3), solref=_vec(a["solref"]), solimp=_vec(a["solimp"], 5),
+                          friction=_vec_d(a["friction"], _GEOM_DEFAULTS["friction"]), solref=_vec_d(a["solref"], _GEOM_DEFAULTS["solref"]),
+                          solimp=_vec_d(a["solimp"], _GEOM_DEFAULTS["solimp"]),
                           margin=float(a["margin"]), gap=float(a["gap"]), solmix=float(a["solmix"]),
                           condim=int(a["condim"]), contype=int(a["contype"]),
                           conaffinity=int(a["conaffinity"]), group=int(a["group"]),
@@ -201,7 +210,8 @@ def compile_mjcf(path: str, sim_dt: float = 0.005, Kp: float = 40.0, Kd: float =
                                    pos=_vec(a["pos"]), range=rng, damping=float(a["damping"]),
                                    armature=float(a["armature"]), frictionloss=float(a["frictionloss"]),
                                    stiffness=float(a["stiffness"]),
-                                   solref=_vec(a["solreflimit"]), solimp=_vec(a["solimplimit"], 5),
+                                   solref=_vec_d(a["solreflimit"], _JOINT_DEFAULTS["solreflimit"]),
+                                   solimp=_vec_d(a["solimplimit"], _JOINT_DEFAULTS["solimplimit"]),
                                    margin=float(a["margin"])))
                 b["joints"].append(len(joints) - 1)
             elif c.tag == "geom":
