@@ -148,11 +148,24 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cores():
+    """Usable host cores: the smaller of the affinity mask and the cgroup CPU quota (the GPU box shows 256 CPUs
+    but grants a 16-CPU quota)."""
+    c = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            c = min(c, max(1, int(round(int(q) / int(p)))))
+    except Exception:
+        pass
+    return c
+
+
 def cpu_baseline(args, cfg, terrain, task, n):
     """The build's CPU restatement (oracle/, fp32, OpenMP over envs) on a bounded sample of the same workload."""
     from oracle import oracle
     from phase_guided_terrain_traversal_amd import abi, configs, mjcf
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     cfg2 = dict(cfg); cfg2["autoreset"] = 1
     cs, ms = abi.config_struct(cfg2), abi.model_struct(mjcf.load_model(task))
     hb = oracle.HostBuffers(n, with_variant=terrain is not None, debug=False)

@@ -220,6 +220,7 @@ typedef struct PgttBuffers {
   const float*   box_friction;  /* [PGTT_MAX_BOX][N] sliding friction per env per box, or NULL */
   int32_t* dbg_contact;  /* [N][PGTT_NCON][2] (foot 0..3 FL,FR,RL,RR ; geom: -1 plane, box idx, -2 none) or NULL */
   float*   dbg_dist;     /* [N][PGTT_NCON] or NULL */
+  int32_t* dbg_niter;    /* [N] max Newton iterations over the substeps of the last physics call (== iterations => truncated), or NULL */
 } PgttBuffers;
 
 typedef struct pgtt_env* pgtt_handle;

@@ -271,6 +271,7 @@ typedef struct PgttOraclePostIn {
     if (B->dbg_contact) for (int c = 0; c < 8; c++) {                                                                    \
       B->dbg_contact[(e*8 + c)*2] = d->contact[c].foot; B->dbg_contact[(e*8 + c)*2 + 1] = d->contact[c].box; }           \
     if (B->dbg_dist) for (int c = 0; c < 8; c++) B->dbg_dist[e*8 + c] = (float)d->contact[c].dist;                       \
+    if (B->dbg_niter) B->dbg_niter[e] = d->solver_niter_max > d->solver_niter ? d->solver_niter_max : d->solver_niter;   \
   }                                                                                                                      \
   static void env_ctx_##SUF(const PgttConfig* cfg, const PgttModel* m, const float* terrain, int T, int Bx, const PgttBuffers* B, \
                             long N, long e, uint64_t seed, int64_t off, OParams_##SUF* p, float* bf, OEnvCtx_##SUF* c) { \

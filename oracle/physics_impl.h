@@ -78,6 +78,7 @@ typedef struct F(OData) {
   /* solver outputs */
   R qacc[ONV], efc_force[ONEFC], qfrc_constraint[ONV];
   int solver_niter;
+  int solver_niter_max;          /* max over the substeps of env_step */
   R cacc_base[6];
   R sensordata[49];
 } F(OData);
@@ -897,9 +898,11 @@ static void F(euler)(const PgttModel* m, F(OData)* d) {
 /* mjx_env.step(model, data, action, n_substeps): scan of { ctrl <- action ; mjx.step } */
 static void F(env_step)(const PgttModel* m, const F(OParams)* p, const float* boxes, const float* box_friction, int nbox,
                         F(OData)* d, const R* ctrl, int nsub) {
+  d->solver_niter_max = 0;
   for (int s = 0; s < nsub; s++) {
     for (int a = 0; a < 12; a++) d->ctrl[a] = ctrl[a];
     F(forward)(m, p, boxes, box_friction, nbox, d);
+    if (d->solver_niter > d->solver_niter_max) d->solver_niter_max = d->solver_niter;
     F(euler)(m, d);
   }
 }

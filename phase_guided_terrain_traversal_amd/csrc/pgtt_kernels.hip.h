@@ -85,6 +85,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
     boxes = a.terrain + (long)v * a.B;
     nbox = a.B;
   }
+  s.niter = 0; s.niter_max = 0;
   Physics<HAS_DR> ph(m, em, s);
   Solver sol(m, s);
   const int nsub = MODE == MODE_STEP ? cfg->n_substeps : 1;
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
 #pragma unroll
         for (int c = 0; c < 8; c++) a.buf.dbg_dist[(long)e * 8 + c] = s.con[c].dist;
       }
+      if (a.buf.dbg_niter) a.buf.dbg_niter[e] = s.niter_max;
     }
     if (MODE == MODE_STEP) {
       // ---- semi-implicit Euler (eulerdamp disabled)

@@ -389,6 +389,7 @@ struct Sim {
   int ncon_box;
   // outputs
   float qacc[18];
+  int niter, niter_max;
 };
 
 PG_INL float sel4(int l, float a, float b, float c, float d) { return l == 0 ? a : (l == 1 ? b : (l == 2 ? c : d)); }
@@ -651,7 +652,12 @@ struct Physics {
 #pragma unroll
     for (int k = 4; k < 8; k++) { s.con[k].leg = -1; s.con[k].box = -2; s.con[k].dist = 1.f; s.con[k].D = 0.f; s.con[k].row_active = false; s.con[k].mu = 0.f;
 #pragma unroll
-      for (int r4 = 0; r4 < 4; r4++) s.con[k].aref[r4] = 0.f; }
+      for (int r4 = 0; r4 < 4; r4++) s.con[k].aref[r4] = 0.f;
+      // an unused slot may still be visited (the slot count is wave-uniform): keep its Jacobian finite
+#pragma unroll
+      for (int a3 = 0; a3 < 3; a3++)
+#pragma unroll
+        for (int k9 = 0; k9 < 9; k9++) s.con[k].J[a3][k9] = 0.f; }
     s.ncon_box = 0;
     if (boxes == nullptr || nbox <= 0) return;
     const int maxp = m->max_geom_pairs, maxc = m->max_contact_points;
@@ -992,6 +998,7 @@ struct Solver {
     }
 #pragma unroll
     for (int i = 0; i < 18; i++) { s.qacc[i] = qacc[i]; s.warm[i] = qacc[i]; }
+    s.niter = niter; s.niter_max = niter > s.niter_max ? niter : s.niter_max;
   }
 };
 

@@ -63,6 +63,7 @@ class Joystick:
         if debug_contacts:
             self.buffers["dbg_contact"] = torch.zeros((n, abi.NCON * 2), dtype=torch.int32, device=self.device)
             self.buffers["dbg_dist"] = torch.zeros((n, abi.NCON), dtype=torch.float32, device=self.device)
+            self.buffers["dbg_niter"] = torch.zeros((n,), dtype=torch.int32, device=self.device)
         self._bind()
         self._seed = 0
 
