@@ -94,9 +94,12 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
     ph.position_stage();
     ph.velocity_stage();
     ph.constraint_stage(boxes, nbox, a.buf.box_friction, N, e);
-    sol.solve();
-    if (sub == nsub - 1) {
-      // ---- sensors of the last forward (pre-integration state), written as the "frame"
+    // ---- sensors of the last forward (pre-integration state) are written BEFORE the solve so that the kinematic
+    //      state does not stay live across the Newton loop; only the accelerometer needs qacc and is kept as an
+    //      affine map acc = acc0 + A qacc[0:6]
+    float accA[3][6], acc0[3];
+    const bool last = sub == nsub - 1;
+    if (last) {
       float* __restrict__ Fr = a.buf.frame;
       V3 w = s.cvel[0].a, vl = s.cvel[0].l;
       V3 dif = s.imu - s.com;
@@ -105,37 +108,34 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
       V3 llin = mtmul(s.R0, glin);
       S6 cacc{v3(0, 0, 0), v3(-m->gravity[0], -m->gravity[1], -m->gravity[2])};
 #pragma unroll
+      for (int k = 0; k < 3; k++) cacc = cacc + s.cddr[k] * s.qvel[3 + k];
+      V3 a0 = mtmul(s.R0, cacc.l - cross(dif, cacc.a)) + cross(gyro, llin);
+      acc0[0] = a0.x; acc0[1] = a0.y; acc0[2] = a0.z;
+#pragma unroll
       for (int k = 0; k < 3; k++) {
-        cacc = cacc + s.cddr[k] * s.qvel[3 + k] + s.cdr[k] * s.qacc[3 + k];
+        V3 ct = mtmul(s.R0, v3(k == 0, k == 1, k == 2));
+        V3 cr = mtmul(s.R0, s.cdr[k].l - cross(dif, s.cdr[k].a));
+        accA[0][k] = ct.x; accA[1][k] = ct.y; accA[2][k] = ct.z;
+        accA[0][3 + k] = cr.x; accA[1][3 + k] = cr.y; accA[2][3 + k] = cr.z;
       }
-      cacc.l = cacc.l + v3(s.qacc[0], s.qacc[1], s.qacc[2]);
-      V3 acc = mtmul(s.R0, cacc.l - cross(dif, cacc.a)) + cross(gyro, llin);
-      float fr[PGTT_NFRAME];
-      fr[PGTT_F_GYRO] = gyro.x; fr[PGTT_F_GYRO + 1] = gyro.y; fr[PGTT_F_GYRO + 2] = gyro.z;
-      fr[PGTT_F_ACCEL] = acc.x; fr[PGTT_F_ACCEL + 1] = acc.y; fr[PGTT_F_ACCEL + 2] = acc.z;
-      fr[PGTT_F_GLOBAL_LINVEL] = glin.x; fr[PGTT_F_GLOBAL_LINVEL + 1] = glin.y; fr[PGTT_F_GLOBAL_LINVEL + 2] = glin.z;
-      fr[PGTT_F_GLOBAL_ANGVEL] = w.x; fr[PGTT_F_GLOBAL_ANGVEL + 1] = w.y; fr[PGTT_F_GLOBAL_ANGVEL + 2] = w.z;
-      fr[PGTT_F_LOCAL_LINVEL] = llin.x; fr[PGTT_F_LOCAL_LINVEL + 1] = llin.y; fr[PGTT_F_LOCAL_LINVEL + 2] = llin.z;
-      fr[PGTT_F_UPVECTOR] = s.R0.m[2]; fr[PGTT_F_UPVECTOR + 1] = s.R0.m[5]; fr[PGTT_F_UPVECTOR + 2] = s.R0.m[8];
-      fr[PGTT_F_GRAVITY] = -s.R0.m[6]; fr[PGTT_F_GRAVITY + 1] = -s.R0.m[7]; fr[PGTT_F_GRAVITY + 2] = -s.R0.m[8];
+      auto put3 = [&](int row, V3 v) { Fr[row * (long)N + e] = v.x; Fr[(row + 1) * (long)N + e] = v.y; Fr[(row + 2) * (long)N + e] = v.z; };
+      put3(PGTT_F_GYRO, gyro); put3(PGTT_F_GLOBAL_LINVEL, glin); put3(PGTT_F_GLOBAL_ANGVEL, w); put3(PGTT_F_LOCAL_LINVEL, llin);
+      put3(PGTT_F_UPVECTOR, v3(s.R0.m[2], s.R0.m[5], s.R0.m[8]));
+      put3(PGTT_F_GRAVITY, v3(-s.R0.m[6], -s.R0.m[7], -s.R0.m[8]));
 #pragma unroll
       for (int f = 0; f < 4; f++) {
         const int l = f ^ 1;                              // FR,FL,RR,RL -> legs 1,0,3,2
-        V3 p = mtmul(s.R0, s.sitef[l] - s.imu);
-        fr[PGTT_F_FEET_POS + 3 * f] = p.x; fr[PGTT_F_FEET_POS + 3 * f + 1] = p.y; fr[PGTT_F_FEET_POS + 3 * f + 2] = p.z;
+        put3(PGTT_F_FEET_POS + 3 * f, mtmul(s.R0, s.sitef[l] - s.imu));
         S6 cv = s.cvel[3 + 3 * l];
-        V3 fv = cv.l - cross(s.sitef[l] - s.com, cv.a);
-        fr[PGTT_F_FEET_VEL + 3 * f] = fv.x; fr[PGTT_F_FEET_VEL + 3 * f + 1] = fv.y; fr[PGTT_F_FEET_VEL + 3 * f + 2] = fv.z;
+        put3(PGTT_F_FEET_VEL + 3 * f, cv.l - cross(s.sitef[l] - s.com, cv.a));
         bool touching = false;
 #pragma unroll
         for (int c = 0; c < 8; c++) touching = touching || (s.con[c].leg == l && s.con[c].box != -2 && s.con[c].dist < 0.f);
-        fr[PGTT_F_CONTACT + f] = touching ? 1.0f : 0.0f;
-        fr[PGTT_F_FOOT_SITE_Z + f] = s.sitef[l].z;
+        Fr[(PGTT_F_CONTACT + f) * (long)N + e] = touching ? 1.0f : 0.0f;
+        Fr[(PGTT_F_FOOT_SITE_Z + f) * (long)N + e] = s.sitef[l].z;
       }
 #pragma unroll
-      for (int i = 0; i < 12; i++) fr[PGTT_F_ACT_FORCE + i] = s.act_force[i];
-#pragma unroll
-      for (int i = 0; i < PGTT_NFRAME; i++) Fr[i * (long)N + e] = fr[i];
+      for (int i = 0; i < 12; i++) Fr[(PGTT_F_ACT_FORCE + i) * (long)N + e] = s.act_force[i];
       if (a.buf.dbg_contact) {
 #pragma unroll
         for (int c = 0; c < 8; c++) { a.buf.dbg_contact[((long)e * 8 + c) * 2] = s.con[c].leg; a.buf.dbg_contact[((long)e * 8 + c) * 2 + 1] = s.con[c].box; }
@@ -143,6 +143,17 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
       if (a.buf.dbg_dist) {
 #pragma unroll
         for (int c = 0; c < 8; c++) a.buf.dbg_dist[(long)e * 8 + c] = s.con[c].dist;
+      }
+    }
+    sol.solve();
+    if (last) {
+      float* __restrict__ Fr = a.buf.frame;
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        float v = acc0[r];
+#pragma unroll
+        for (int k = 0; k < 6; k++) v += accA[r][k] * s.qacc[k];
+        Fr[(PGTT_F_ACCEL + r) * (long)N + e] = v;
       }
       if (a.buf.dbg_niter) a.buf.dbg_niter[e] = s.niter_max;
     }

@@ -666,6 +666,7 @@ struct Physics {
     float keyC[4];
 #pragma unroll
     for (int l = 0; l < 4; l++) keyC[l] = m->foot_radius[l] + m->box_rbound;
+#pragma unroll 4
     for (int b = 0; b < nbox; b++) {
       const float4 A = reinterpret_cast<const float4*>(boxes + b)[0];
 #pragma unroll
@@ -689,6 +690,7 @@ struct Physics {
 #pragma unroll
     for (int i = 0; i < kMaxPen; i++) rank[i] = 0;
     if (broad) {
+#pragma unroll 4
       for (int b = 0; b < nbox; b++) {
         const float4 A = reinterpret_cast<const float4*>(boxes + b)[0];
 #pragma unroll
@@ -869,7 +871,7 @@ struct Solver {
 
   struct LSPoint { float alpha, cost, d0, d1; };
 
-  PG_INL void linesearch() {
+  PG_INL void linesearch(bool frozen) {
     float sn = 0.f;
 #pragma unroll
     for (int i = 0; i < 18; i++) sn += search[i] * search[i];
@@ -940,14 +942,15 @@ struct Solver {
     }
     bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
     float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
-    float ia = improved ? alpha : 0.f;
+    float ia = (improved && !frozen) ? alpha : 0.f;
 #pragma unroll
     for (int i = 0; i < 18; i++) { qacc[i] += search[i] * ia; Ma[i] += mv[i] * ia; }
 #pragma unroll
     for (int j = 0; j < 12; j++) jar_lim[j] += jv_lim[j] * ia;
-    for (int c = 0; c < 4 + nbox_slots; c++)
+    for (int c = 0; c < 4 + nbox_slots; c++) {
 #pragma unroll
       for (int r = 0; r < 4; r++) jar_con[c][r] += jv_con[c][r] * ia;
+    }
   }
 
   PG_INL void solve() {
@@ -970,31 +973,12 @@ struct Solver {
       for (int i = 0; i < 18; i++) gn += grad[i] * grad[i];
       bool done = niter >= m->iterations || ((prev_cost - cost) / scale < m->tolerance) || (sqrtf(gn) / scale < m->tolerance);
       if (__ballot(!done) == 0ull) break;
-      // lanes that are done keep their state: run the iteration on copies and commit under the predicate
-      float kq[18], kMa[18], kg[18], ks[18], kqfc[18], kjl[12], kjc[8][4];
-      float kgauss = gauss, kcost = cost, kprev = prev_cost;
-#pragma unroll
-      for (int i = 0; i < 18; i++) { kq[i] = qacc[i]; kMa[i] = Ma[i]; kg[i] = grad[i]; ks[i] = search[i]; kqfc[i] = qfc[i]; }
-#pragma unroll
-      for (int j = 0; j < 12; j++) kjl[j] = jar_lim[j];
-      for (int c = 0; c < 4 + nbox_slots; c++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) kjc[c][r] = jar_con[c][r];
-      linesearch();
+      // lanes whose solve is finished take a zero-length step: every quantity is then recomputed from unchanged
+      // inputs (bitwise identical), improvement becomes 0 and the lane stays finished
+      linesearch(done);
       update_constraint();
       update_gradient();
-      if (done) {
-#pragma unroll
-        for (int i = 0; i < 18; i++) { qacc[i] = kq[i]; Ma[i] = kMa[i]; grad[i] = kg[i]; search[i] = ks[i]; qfc[i] = kqfc[i]; }
-#pragma unroll
-        for (int j = 0; j < 12; j++) jar_lim[j] = kjl[j];
-        for (int c = 0; c < 4 + nbox_slots; c++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) jar_con[c][r] = kjc[c][r];
-        gauss = kgauss; cost = kcost; prev_cost = kprev;
-      } else {
-        niter++;
-      }
+      if (!done) niter++;
     }
 #pragma unroll
     for (int i = 0; i < 18; i++) { s.qacc[i] = qacc[i]; s.warm[i] = qacc[i]; }
