@@ -60,7 +60,7 @@ pgtt::KArgs make_args(pgtt_env* h, const unsigned char* mask, float yaw_override
 
 template <int MODE>
 void launch_physics(pgtt_env* h, const pgtt::KArgs& a, const float* action, hipStream_t st) {
-  const int nb = (h->N + 63) / 64;
+  const int nb = (h->N + 15) / 16;                      // one env per quad of lanes: 16 envs per 64-thread block
   const bool dr = h->buf.params != nullptr, terr = h->T > 0;
   if (MODE == 0) {
     if (dr && terr) pgtt_launch_physics_0_1_1(nb, st, a, action); else if (dr) pgtt_launch_physics_0_1_0(nb, st, a, action);

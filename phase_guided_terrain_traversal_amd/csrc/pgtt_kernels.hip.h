@@ -1,6 +1,7 @@
 // pgtt_kernels.hip.h — __global__ kernels of libpgtt.so (gfx950).
 //
-//   physics_kernel  : one env per lane (64-thread blocks).  MODE_STEP = mjx_env.step (n_substeps x
+//   physics_kernel  : one env per QUAD of lanes (lane = leg; 16 envs per 64-thread block), DPP quad reductions,
+//                     no LDS / scratch.  MODE_STEP = mjx_env.step (n_substeps x
 //                     {forward, Euler}) + sensor frame + contact flags; MODE_FORWARD = one mjx.forward
 //                     (reset path).  Reference: go2/joystick_pgtt.py:146-148, :72, :78.
 //   observe_kernel  : one env per WAVE.  13x9 height scan with the terrain variant's boxes read through
@@ -10,7 +11,7 @@
 //                     Reference: go2/joystick_pgtt.py:156-231, :238-370, go2/heightmap.py:25-67.
 //   reset_pose_kernel: pose / velocity sampling of Joystick.reset (go2/joystick_pgtt.py:51-70).
 #pragma once
-#include "pgtt_physics.hip.h"
+#include "pgtt_physics_quad.hip.h"
 
 namespace pgtt {
 
@@ -53,30 +54,35 @@ PG_INL int exp_timer(unsigned long long seed, unsigned env, unsigned epoch, unsi
 
 enum { MODE_STEP = 0, MODE_FORWARD = 1 };
 
-// ------------------------------------------------------------------ physics
+// ------------------------------------------------------------------ physics: one env per QUAD of lanes (16 envs per wave)
 template <int MODE, bool HAS_DR, bool HAS_TERRAIN>
 __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __restrict__ action) {
-  const int e = blockIdx.x * 64 + threadIdx.x;
   const int N = a.N;
-  if (e >= N) return;
-  if (MODE != MODE_STEP && a.mask && !a.mask[e]) return;
+  const int l = threadIdx.x & 3;                       // leg FL,FR,RL,RR
+  int e = blockIdx.x * 16 + (threadIdx.x >> 2);
+  bool valid = e < N;
+  if (!valid) e = N - 1;                               // keep whole quads running (DPP), suppress the stores
+  if (MODE != MODE_STEP && a.mask && !a.mask[e]) valid = false;
   const PgttModel* __restrict__ m = a.model;
   const PgttConfig* __restrict__ cfg = a.cfg;
   float* __restrict__ S = a.buf.state;
+  const bool lead = valid && l == 0;
 
-  EnvModel em;
-  load_env_model<HAS_DR>(m, a.buf.params, N, e, em);
-  Sim s;
+  QEnvModel em;
+  qload_env_model<HAS_DR>(m, a.buf.params, N, e, l, em);
+  QSim s;
 #pragma unroll
-  for (int i = 0; i < 19; i++) s.qpos[i] = S[(PGTT_S_QPOS + i) * (long)N + e];
+  for (int i = 0; i < 7; i++) s.qb[i] = S[(PGTT_S_QPOS + i) * (long)N + e];
 #pragma unroll
-  for (int i = 0; i < 18; i++) { s.qvel[i] = S[(PGTT_S_QVEL + i) * (long)N + e]; s.warm[i] = S[(PGTT_S_QWARM + i) * (long)N + e]; }
-  if (MODE == MODE_STEP) {
+  for (int i = 0; i < 6; i++) { s.vb[i] = S[(PGTT_S_QVEL + i) * (long)N + e]; s.wb[i] = S[(PGTT_S_QWARM + i) * (long)N + e]; }
 #pragma unroll
-    for (int i = 0; i < 12; i++) s.ctrl[i] = m->key_qpos[7 + i] + action[(long)e * 12 + i] * cfg->action_scale;
-  } else {
-#pragma unroll
-    for (int i = 0; i < 12; i++) s.ctrl[i] = s.qpos[7 + i];      // mjx_env.init(ctrl = qpos[7:])
+  for (int k = 0; k < 3; k++) {
+    const int j = 3 * l + k, ac = 3 * (l ^ 1) + k;     // joint index, actuator index driving it
+    s.ql[k] = S[(PGTT_S_QPOS + 7 + j) * (long)N + e];
+    s.vl[k] = S[(PGTT_S_QVEL + 6 + j) * (long)N + e];
+    s.wl[k] = S[(PGTT_S_QWARM + 6 + j) * (long)N + e];
+    if (MODE == MODE_STEP) s.ctrl[k] = m->key_qpos[7 + ac] + action[(long)e * 12 + ac] * cfg->action_scale;
+    else s.ctrl[k] = S[(PGTT_S_QPOS + 7 + ac) * (long)N + e];          // mjx_env.init(ctrl = qpos[7:])
   }
   const TerrainBox* boxes = nullptr;
   int nbox = 0;
@@ -86,29 +92,28 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
     nbox = a.B;
   }
   s.niter = 0; s.niter_max = 0;
-  Physics<HAS_DR> ph(m, em, s);
-  Solver sol(m, s);
+  QPhysics ph(m, em, s, l);
+  QSolver sol(m, s);
   const int nsub = MODE == MODE_STEP ? cfg->n_substeps : 1;
   const float dt = m->timestep;
   for (int sub = 0; sub < nsub; sub++) {
     ph.position_stage();
     ph.velocity_stage();
     ph.constraint_stage(boxes, nbox, a.buf.box_friction, N, e);
-    // ---- sensors of the last forward (pre-integration state) are written BEFORE the solve so that the kinematic
-    //      state does not stay live across the Newton loop; only the accelerometer needs qacc and is kept as an
-    //      affine map acc = acc0 + A qacc[0:6]
+    // ---- sensors of the last forward (pre-integration state), written BEFORE the solve; the accelerometer is
+    //      kept as an affine map of qacc[0:6]
     float accA[3][6], acc0[3];
     const bool last = sub == nsub - 1;
     if (last) {
       float* __restrict__ Fr = a.buf.frame;
-      V3 w = s.cvel[0].a, vl = s.cvel[0].l;
+      V3 w = s.cvel0.a, vl = s.cvel0.l;
       V3 dif = s.imu - s.com;
       V3 gyro = mtmul(s.R0, w);
       V3 glin = vl - cross(dif, w);
       V3 llin = mtmul(s.R0, glin);
       S6 cacc{v3(0, 0, 0), v3(-m->gravity[0], -m->gravity[1], -m->gravity[2])};
 #pragma unroll
-      for (int k = 0; k < 3; k++) cacc = cacc + s.cddr[k] * s.qvel[3 + k];
+      for (int k = 0; k < 3; k++) cacc = cacc + s.cddr[k] * s.vb[3 + k];
       V3 a0 = mtmul(s.R0, cacc.l - cross(dif, cacc.a)) + cross(gyro, llin);
       acc0[0] = a0.x; acc0[1] = a0.y; acc0[2] = a0.z;
 #pragma unroll
@@ -119,40 +124,47 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
         accA[0][3 + k] = cr.x; accA[1][3 + k] = cr.y; accA[2][3 + k] = cr.z;
       }
       auto put3 = [&](int row, V3 v) { Fr[row * (long)N + e] = v.x; Fr[(row + 1) * (long)N + e] = v.y; Fr[(row + 2) * (long)N + e] = v.z; };
-      put3(PGTT_F_GYRO, gyro); put3(PGTT_F_GLOBAL_LINVEL, glin); put3(PGTT_F_GLOBAL_ANGVEL, w); put3(PGTT_F_LOCAL_LINVEL, llin);
-      put3(PGTT_F_UPVECTOR, v3(s.R0.m[2], s.R0.m[5], s.R0.m[8]));
-      put3(PGTT_F_GRAVITY, v3(-s.R0.m[6], -s.R0.m[7], -s.R0.m[8]));
+      if (lead) {
+        put3(PGTT_F_GYRO, gyro); put3(PGTT_F_GLOBAL_LINVEL, glin); put3(PGTT_F_GLOBAL_ANGVEL, w); put3(PGTT_F_LOCAL_LINVEL, llin);
+        put3(PGTT_F_UPVECTOR, v3(s.R0.m[2], s.R0.m[5], s.R0.m[8]));
+        put3(PGTT_F_GRAVITY, v3(-s.R0.m[6], -s.R0.m[7], -s.R0.m[8]));
+      }
+      // own foot: sensor order FR,FL,RR,RL = leg ^ 1
+      const int f = l ^ 1;
+      bool touching = false;
 #pragma unroll
-      for (int f = 0; f < 4; f++) {
-        const int l = f ^ 1;                              // FR,FL,RR,RL -> legs 1,0,3,2
-        put3(PGTT_F_FEET_POS + 3 * f, mtmul(s.R0, s.sitef[l] - s.imu));
-        S6 cv = s.cvel[3 + 3 * l];
-        put3(PGTT_F_FEET_VEL + 3 * f, cv.l - cross(s.sitef[l] - s.com, cv.a));
-        bool touching = false;
-#pragma unroll
-        for (int c = 0; c < 8; c++) touching = touching || (s.con[c].leg == l && s.con[c].box != -2 && s.con[c].dist < 0.f);
+      for (int c = 0; c <= kMaxB; c++) touching = touching || (s.con[c].on && s.con[c].dist < 0.f);
+      // box-contact slot numbering of the debug record: own contacts follow those of the lower legs
+      const int n0 = quad_bcast<0>(s.nbox), n1 = quad_bcast<1>(s.nbox), n2 = quad_bcast<2>(s.nbox), n3 = quad_bcast<3>(s.nbox);
+      const int off = l == 0 ? 0 : (l == 1 ? n0 : (l == 2 ? n0 + n1 : n0 + n1 + n2)), total = n0 + n1 + n2 + n3;
+      if (valid) {
+        put3(PGTT_F_FEET_POS + 3 * f, mtmul(s.R0, s.sitef - s.imu));
+        S6 cv = s.cvell[2];
+        put3(PGTT_F_FEET_VEL + 3 * f, cv.l - cross(s.sitef - s.com, cv.a));
         Fr[(PGTT_F_CONTACT + f) * (long)N + e] = touching ? 1.0f : 0.0f;
-        Fr[(PGTT_F_FOOT_SITE_Z + f) * (long)N + e] = s.sitef[l].z;
-      }
+        Fr[(PGTT_F_FOOT_SITE_Z + f) * (long)N + e] = s.sitef.z;
 #pragma unroll
-      for (int i = 0; i < 12; i++) Fr[(PGTT_F_ACT_FORCE + i) * (long)N + e] = s.act_force[i];
-      if (a.buf.dbg_contact) {
+        for (int k = 0; k < 3; k++) Fr[(PGTT_F_ACT_FORCE + 3 * f + k) * (long)N + e] = s.act_force[k];
+        if (a.buf.dbg_contact && a.buf.dbg_dist) {
+          int* dc = a.buf.dbg_contact + (long)e * 16; float* dd = a.buf.dbg_dist + (long)e * 8;
+          dc[2 * l] = l; dc[2 * l + 1] = -1; dd[l] = s.con[0].dist;
 #pragma unroll
-        for (int c = 0; c < 8; c++) { a.buf.dbg_contact[((long)e * 8 + c) * 2] = s.con[c].leg; a.buf.dbg_contact[((long)e * 8 + c) * 2 + 1] = s.con[c].box; }
-      }
-      if (a.buf.dbg_dist) {
+          for (int k = 0; k < kMaxB; k++) if (k < s.nbox && off + k < 4) { dc[2 * (4 + off + k)] = l; dc[2 * (4 + off + k) + 1] = s.con[1 + k].box; dd[4 + off + k] = s.con[1 + k].dist; }
+          if (l == 0) {
 #pragma unroll
-        for (int c = 0; c < 8; c++) a.buf.dbg_dist[(long)e * 8 + c] = s.con[c].dist;
+            for (int k = 0; k < 4; k++) if (k >= total) { dc[2 * (4 + k)] = -1; dc[2 * (4 + k) + 1] = -2; dd[4 + k] = 1.0f; }
+          }
+        }
       }
     }
     sol.solve();
-    if (last) {
+    if (last && lead) {
       float* __restrict__ Fr = a.buf.frame;
 #pragma unroll
       for (int r = 0; r < 3; r++) {
         float v = acc0[r];
 #pragma unroll
-        for (int k = 0; k < 6; k++) v += accA[r][k] * s.qacc[k];
+        for (int k = 0; k < 6; k++) v += accA[r][k] * s.qacc_b[k];
         Fr[(PGTT_F_ACCEL + r) * (long)N + e] = v;
       }
       if (a.buf.dbg_niter) a.buf.dbg_niter[e] = s.niter_max;
@@ -160,32 +172,47 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
     if (MODE == MODE_STEP) {
       // ---- semi-implicit Euler (eulerdamp disabled)
 #pragma unroll
-      for (int i = 0; i < 18; i++) s.qvel[i] = s.qvel[i] + s.qacc[i] * dt;
+      for (int i = 0; i < 6; i++) s.vb[i] = s.vb[i] + s.qacc_b[i] * dt;
 #pragma unroll
-      for (int i = 0; i < 3; i++) s.qpos[i] = s.qpos[i] + dt * s.qvel[i];
-      V3 wv = v3(s.qvel[3], s.qvel[4], s.qvel[5]);
+      for (int k = 0; k < 3; k++) s.vl[k] = s.vl[k] + s.qacc_l[k] * dt;
+#pragma unroll
+      for (int i = 0; i < 3; i++) s.qb[i] = s.qb[i] + dt * s.vb[i];
+      V3 wv = v3(s.vb[3], s.vb[4], s.vb[5]);
       float nn = normalize3(wv);
       float sn, cs; sincosf(0.5f * (dt * nn), &sn, &cs);
-      Q4 q{s.qpos[3], s.qpos[4], s.qpos[5], s.qpos[6]};
-      Q4 q2 = qmul(q, Q4{cs, wv.x * sn, wv.y * sn, wv.z * sn});
+      Q4 q2 = qmul(Q4{s.qb[3], s.qb[4], s.qb[5], s.qb[6]}, Q4{cs, wv.x * sn, wv.y * sn, wv.z * sn});
       normalize4(q2);
-      s.qpos[3] = q2.w; s.qpos[4] = q2.x; s.qpos[5] = q2.y; s.qpos[6] = q2.z;
+      s.qb[3] = q2.w; s.qb[4] = q2.x; s.qb[5] = q2.y; s.qb[6] = q2.z;
 #pragma unroll
-      for (int j = 0; j < 12; j++) s.qpos[7 + j] = s.qpos[7 + j] + dt * s.qvel[6 + j];
+      for (int k = 0; k < 3; k++) s.ql[k] = s.ql[k] + dt * s.vl[k];
     }
   }
+  if (!valid) return;
   if (MODE == MODE_STEP || a.write_qpos) {
+    if (l == 0) {
 #pragma unroll
-    for (int i = 0; i < 19; i++) S[(PGTT_S_QPOS + i) * (long)N + e] = s.qpos[i];
+      for (int i = 0; i < 7; i++) S[(PGTT_S_QPOS + i) * (long)N + e] = s.qb[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) S[(PGTT_S_QPOS + 7 + 3 * l + k) * (long)N + e] = s.ql[k];
   }
   if (MODE == MODE_STEP) {
+    if (l == 0) {
 #pragma unroll
-    for (int i = 0; i < 18; i++) S[(PGTT_S_QVEL + i) * (long)N + e] = s.qvel[i];
+      for (int i = 0; i < 6; i++) S[(PGTT_S_QVEL + i) * (long)N + e] = s.vb[i];
+    }
 #pragma unroll
-    for (int i = 0; i < 12; i++) S[(PGTT_S_MOTOR_TARGETS + i) * (long)N + e] = s.ctrl[i];
+    for (int k = 0; k < 3; k++) {
+      S[(PGTT_S_QVEL + 6 + 3 * l + k) * (long)N + e] = s.vl[k];
+      S[(PGTT_S_MOTOR_TARGETS + 3 * (l ^ 1) + k) * (long)N + e] = s.ctrl[k];
+    }
+  }
+  if (l == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) S[(PGTT_S_QWARM + i) * (long)N + e] = s.wb[i];
   }
 #pragma unroll
-  for (int i = 0; i < 18; i++) S[(PGTT_S_QWARM + i) * (long)N + e] = s.warm[i];
+  for (int k = 0; k < 3; k++) S[(PGTT_S_QWARM + 6 + 3 * l + k) * (long)N + e] = s.wl[k];
 }
 
 // ------------------------------------------------------------------ reset: pose sampling (go2/joystick_pgtt.py:51-70)

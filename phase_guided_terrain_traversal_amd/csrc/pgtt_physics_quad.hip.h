@@ -1,0 +1,814 @@
+// pgtt_physics_quad.hip.h — the physics of one environment spread over a QUAD of lanes (gfx950, wave64).
+//
+// Layout: lane = 4*q + l, q = env within the wave (16 envs per wave), l = leg (FL,FR,RL,RR = body-tree order).
+// Lane l owns leg l: its 3 links, 3 dofs, 3 joint-limit rows, its foot's plane contact and its foot's box
+// contacts, the leg blocks M_ll (3x3) / M_lb (3x6) of the arrowhead inertia and of the Newton Hessian.
+// Everything that belongs to the floating base (pose, COM, 6x6 base block, base parts of every 18-vector) is
+// REPLICATED in the four lanes and kept bitwise identical: cross-lane sums use a symmetric two-step DPP
+// butterfly (quad_perm [1,0,3,2] then [2,3,0,1]), which returns the same bits in all four lanes.
+// No LDS, no scratch: the per-lane working set (~300 floats) lives in VGPRs, and a 4096-env batch becomes
+// 256 waves (one per CU) instead of 64.
+//
+// Same arithmetic contract as the one-env-per-lane version (see pgtt_physics.hip.h header): MJX forward +
+// Euler for the Go2 tree, active contact set identical to MJX's top-k semantics, Newton(5) x linesearch(5).
+#pragma once
+#include "pgtt_physics.hip.h"
+
+namespace pgtt {
+
+// ------------------------------------------------------------------ quad cross-lane primitives (DPP, VALU only)
+template <int CTRL>
+PG_INL float dpp_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+PG_INL int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
+PG_INL float quad_sum(float x) { x += dpp_f<0xB1>(x); x += dpp_f<0x4E>(x); return x; }
+PG_INL int quad_sum_i(int x) { x += dpp_i<0xB1>(x); x += dpp_i<0x4E>(x); return x; }
+PG_INL V3 quad_sum(V3 a) { return v3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)); }
+template <int J> PG_INL float quad_bcast(float x) { return dpp_f<J * 0x55>(x); }
+template <int J> PG_INL int quad_bcast(int x) { return dpp_i<J * 0x55>(x); }
+
+constexpr int kMaxB = 4;          // box contacts one foot can hold (= max_contact_points of the reference)
+constexpr int kMaxPenQ = 4;       // penetrating (foot, box) pairs tracked per foot
+
+struct QArrow { float bb[21]; float lb[18]; float ll[6]; };
+
+struct QContact {
+  bool on;            // slot in use
+  bool row_active;    // dist < margin
+  int box;            // -1 plane, else box index
+  float dist, mu, D;
+  float aref[4];
+  float J[3][9];
+};
+
+struct QSim {
+  // state: base replicated, leg own
+  float qb[7], vb[6], wb[6];
+  float ql[3], vl[3], wl[3];
+  float ctrl[3];
+  // kinematics
+  V3 p0, com, imu; M3 R0;
+  V3 anchor[3], axis[3], footc, sitef;
+  I10 cin0, cinl[3];
+  S6 cdr[3], cdl[3];
+  QArrow M, LM;
+  // velocity
+  S6 cvel0, cvell[3], cddr[3], cddl[3];
+  float qfs_b[6], qfs_l[3], qas_b[6], qas_l[3], act_force[3];
+  // constraints
+  bool lim_active[3]; float lim_sign[3], lim_D[3], lim_aref[3];
+  QContact con[1 + kMaxB];
+  int nbox;
+  // outputs
+  float qacc_b[6], qacc_l[3];
+  int niter, niter_max;
+};
+
+// y = A x
+PG_INL void qarrow_mul(const QArrow& A, const float* xb, const float* xl, float* yb, float* yl) {
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float s = 0.f, t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; j++) s += A.bb[i >= j ? tri(i, j) : tri(j, i)] * xb[j];
+#pragma unroll
+    for (int k = 0; k < 3; k++) t += A.lb[k * 6 + i] * xl[k];
+    yb[i] = s + quad_sum(t);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; i++) s += A.lb[k * 6 + i] * xb[i];
+#pragma unroll
+    for (int j = 0; j < 3; j++) s += A.ll[k >= j ? tri(k, j) : tri(j, k)] * xl[j];
+    yl[k] = s;
+  }
+}
+PG_INL void qarrow_factor(QArrow& A) {
+  float* c = A.ll;
+  float l00 = sqrtf(c[0]);
+  float l10 = c[1] / l00, l20 = c[3] / l00;
+  float l11 = sqrtf(c[2] - l10 * l10);
+  float l21 = (c[4] - l20 * l10) / l11;
+  float l22 = sqrtf(c[5] - l20 * l20 - l21 * l21);
+  c[0] = l00; c[1] = l10; c[2] = l11; c[3] = l20; c[4] = l21; c[5] = l22;
+  float* w = A.lb;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    float w0 = w[k] / l00;
+    float w1 = (w[6 + k] - l10 * w0) / l11;
+    float w2 = (w[12 + k] - l20 * w0 - l21 * w1) / l22;
+    w[k] = w0; w[6 + k] = w1; w[12 + k] = w2;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++)
+      A.bb[tri(i, j)] -= quad_sum(w[i] * w[j] + w[6 + i] * w[6 + j] + w[12 + i] * w[12 + j]);
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    float s = A.bb[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) s -= A.bb[tri(j, k)] * A.bb[tri(j, k)];
+    float d = sqrtf(s);
+    A.bb[tri(j, j)] = d;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      float t = A.bb[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) t -= A.bb[tri(i, k)] * A.bb[tri(j, k)];
+      A.bb[tri(i, j)] = t / d;
+    }
+  }
+}
+PG_INL void qarrow_solve(const QArrow& F, const float* bb, const float* bl, float* xb, float* xl) {
+  const float* c = F.ll;
+  float y0 = bl[0] / c[0];
+  float y1 = (bl[1] - c[1] * y0) / c[2];
+  float y2 = (bl[2] - c[3] * y0 - c[4] * y1) / c[5];
+  float z[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    float rb = bb[i] - quad_sum(F.lb[i] * y0 + F.lb[6 + i] * y1 + F.lb[12 + i] * y2);
+#pragma unroll
+    for (int k = 0; k < i; k++) rb -= F.bb[tri(i, k)] * z[k];
+    z[i] = rb / F.bb[tri(i, i)];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    float s = z[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) s -= F.bb[tri(k, i)] * xb[k];
+    xb[i] = s / F.bb[tri(i, i)];
+  }
+  float t0 = y0, t1 = y1, t2 = y2;
+#pragma unroll
+  for (int k = 0; k < 6; k++) { t0 -= F.lb[k] * xb[k]; t1 -= F.lb[6 + k] * xb[k]; t2 -= F.lb[12 + k] * xb[k]; }
+  float x2 = t2 / c[5];
+  float x1 = (t1 - c[4] * x2) / c[2];
+  float x0 = (t0 - c[1] * x1 - c[3] * x2) / c[0];
+  xl[0] = x0; xl[1] = x1; xl[2] = x2;
+}
+
+// per-env model view for one leg
+struct QEnvModel {
+  float mass0, massl[3];
+  V3 base_ipos;
+  float qpos0j[3], armature[3], damping[3], gain[3], bias1[3];
+  float floor_friction;
+};
+template <bool HAS_DR>
+PG_INL void qload_env_model(const PgttModel* __restrict__ m, const float* __restrict__ prm, int N, int e, int l, QEnvModel& em) {
+  if (HAS_DR) {
+    em.mass0 = prm[(PGTT_P_BODY_MASS + 0) * (long)N + e];
+    em.base_ipos = v3(prm[(PGTT_P_BASE_IPOS + 0) * (long)N + e], prm[(PGTT_P_BASE_IPOS + 1) * (long)N + e], prm[(PGTT_P_BASE_IPOS + 2) * (long)N + e]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int j = 3 * l + k, a = 3 * (l ^ 1) + k;
+      em.massl[k] = prm[(PGTT_P_BODY_MASS + 1 + j) * (long)N + e];
+      em.qpos0j[k] = prm[(PGTT_P_QPOS0 + j) * (long)N + e];
+      em.armature[k] = prm[(PGTT_P_ARMATURE + j) * (long)N + e];
+      em.damping[k] = prm[(PGTT_P_DAMPING + j) * (long)N + e];
+      em.gain[k] = prm[(PGTT_P_GAIN + a) * (long)N + e];
+      em.bias1[k] = prm[(PGTT_P_BIAS1 + a) * (long)N + e];
+    }
+    em.floor_friction = prm[PGTT_P_FLOOR_FRICTION * (long)N + e];
+  } else {
+    em.mass0 = m->body_mass[0];
+    em.base_ipos = v3(m->body_ipos[0][0], m->body_ipos[0][1], m->body_ipos[0][2]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int j = 3 * l + k, a = 3 * (l ^ 1) + k;
+      em.massl[k] = m->body_mass[1 + j]; em.qpos0j[k] = m->qpos0[7 + j]; em.armature[k] = m->dof_armature[6 + j];
+      em.damping[k] = m->dof_damping[6 + j]; em.gain[k] = m->act_gain[a]; em.bias1[k] = m->act_bias[a][1];
+    }
+    em.floor_friction = m->floor_friction[0];
+  }
+}
+
+struct QPen { float dist, key; int idx; V3 pos, n; };
+
+struct QPhysics {
+  const PgttModel* __restrict__ m;
+  const QEnvModel& em;
+  QSim& s;
+  const int l;      // own leg
+  PG_INL QPhysics(const PgttModel* m_, const QEnvModel& em_, QSim& s_, int l_) : m(m_), em(em_), s(s_), l(l_) {}
+
+  PG_INL void body_inertia(int mb, V3 xp, Q4 xq, V3 ipos, float mass, V3& xipos, float* Iw) const {
+    xipos = xp + qrot(ipos, xq);
+    Q4 iq{m->body_iquat[mb][0], m->body_iquat[mb][1], m->body_iquat[mb][2], m->body_iquat[mb][3]};
+    M3 xi = qmat(qmul(xq, iq));
+    float d0 = m->body_inertia[mb][0], d1 = m->body_inertia[mb][1], d2 = m->body_inertia[mb][2];
+    Iw[0] = xi.m[0] * d0 * xi.m[0] + xi.m[1] * d1 * xi.m[1] + xi.m[2] * d2 * xi.m[2];
+    Iw[1] = xi.m[3] * d0 * xi.m[3] + xi.m[4] * d1 * xi.m[4] + xi.m[5] * d2 * xi.m[5];
+    Iw[2] = xi.m[6] * d0 * xi.m[6] + xi.m[7] * d1 * xi.m[7] + xi.m[8] * d2 * xi.m[8];
+    Iw[3] = xi.m[0] * d0 * xi.m[3] + xi.m[1] * d1 * xi.m[4] + xi.m[2] * d2 * xi.m[5];
+    Iw[4] = xi.m[0] * d0 * xi.m[6] + xi.m[1] * d1 * xi.m[7] + xi.m[2] * d2 * xi.m[8];
+    Iw[5] = xi.m[3] * d0 * xi.m[6] + xi.m[4] * d1 * xi.m[7] + xi.m[5] * d2 * xi.m[8];
+    (void)mass;
+  }
+  PG_INL static void make_cinert(V3 xipos, const float* Iw, float mass, V3 com, I10& c) {
+    V3 o = xipos - com; float oo = dot(o, o);
+    c.i[0] = Iw[0] + mass * (oo - o.x * o.x); c.i[1] = Iw[1] + mass * (oo - o.y * o.y); c.i[2] = Iw[2] + mass * (oo - o.z * o.z);
+    c.i[3] = Iw[3] - mass * o.x * o.y; c.i[4] = Iw[4] - mass * o.x * o.z; c.i[5] = Iw[5] - mass * o.y * o.z;
+    c.i[6] = o.x * mass; c.i[7] = o.y * mass; c.i[8] = o.z * mass; c.i[9] = mass;
+  }
+
+  PG_INL void position_stage() {
+    Q4 q0{s.qb[3], s.qb[4], s.qb[5], s.qb[6]};
+    normalize4(q0);
+    s.qb[3] = q0.w; s.qb[4] = q0.x; s.qb[5] = q0.y; s.qb[6] = q0.z;
+    s.p0 = v3(s.qb[0], s.qb[1], s.qb[2]);
+    s.R0 = qmat(q0);
+    V3 xi0, xil[3]; float Iw0[6], Iwl[3][6];
+    body_inertia(0, s.p0, q0, em.base_ipos, em.mass0, xi0, Iw0);
+    s.imu = s.p0 + qrot(v3(m->imu_pos[0], m->imu_pos[1], m->imu_pos[2]), q0);
+    V3 pp = s.p0; Q4 pq = q0;
+    V3 part = v3(0, 0, 0); float pm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int j = 3 * l + k, mb = 1 + j;
+      V3 pos = pp + qrot(v3(m->body_pos[mb][0], m->body_pos[mb][1], m->body_pos[mb][2]), pq);
+      V3 ax = v3(m->jnt_axis[j][0], m->jnt_axis[j][1], m->jnt_axis[j][2]);
+      float ang = s.ql[k] - em.qpos0j[k];
+      float sn, cs; sincosf(0.5f * ang, &sn, &cs);
+      s.axis[k] = qrot(ax, pq);
+      s.anchor[k] = pos;
+      Q4 xq = qmul(pq, Q4{cs, ax.x * sn, ax.y * sn, ax.z * sn});
+      body_inertia(mb, pos, xq, v3(m->body_ipos[mb][0], m->body_ipos[mb][1], m->body_ipos[mb][2]), em.massl[k], xil[k], Iwl[k]);
+      pp = pos; pq = xq;
+    }
+    s.footc = pp + qrot(v3(m->foot_geom_pos[l][0], m->foot_geom_pos[l][1], m->foot_geom_pos[l][2]), pq);
+    s.sitef = pp + qrot(v3(m->foot_site_pos[l][0], m->foot_site_pos[l][1], m->foot_site_pos[l][2]), pq);
+#pragma unroll
+    for (int k = 2; k >= 0; k--) { part = part + xil[k] * em.massl[k]; pm += em.massl[k]; }
+    V3 tot = quad_sum(part) + xi0 * em.mass0;
+    float mt = quad_sum(pm) + em.mass0;
+    s.com = tot * (1.0f / fmaxf(mt, kMinVal));
+    make_cinert(xi0, Iw0, em.mass0, s.com, s.cin0);
+#pragma unroll
+    for (int k = 0; k < 3; k++) make_cinert(xil[k], Iwl[k], em.massl[k], s.com, s.cinl[k]);
+    V3 ob = s.com - s.p0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { V3 a = mcol(s.R0, k); s.cdr[k] = S6{a, cross(a, ob)}; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) s.cdl[k] = S6{s.axis[k], cross(s.axis[k], s.com - s.anchor[k])};
+    // composite inertia of the own leg, then of the whole robot (quad sum), and the arrowhead M
+    I10 crb = s.cinl[2];
+#pragma unroll
+    for (int k = 2; k >= 0; k--) {
+      if (k < 2) {
+#pragma unroll
+        for (int i = 0; i < 10; i++) crb.i[i] += s.cinl[k].i[i];
+      }
+      S6 f = inert_mul(crb, s.cdl[k]);
+#pragma unroll
+      for (int kk = 0; kk <= k; kk++) s.M.ll[tri(k, kk)] = dot6(s.cdl[kk], f);
+      s.M.lb[k * 6 + 0] = f.l.x; s.M.lb[k * 6 + 1] = f.l.y; s.M.lb[k * 6 + 2] = f.l.z;
+#pragma unroll
+      for (int r = 0; r < 3; r++) s.M.lb[k * 6 + 3 + r] = dot6(s.cdr[r], f);
+      s.M.ll[tri(k, k)] += em.armature[k];
+    }
+    I10 crb_base;
+#pragma unroll
+    for (int i = 0; i < 10; i++) crb_base.i[i] = s.cin0.i[i] + quad_sum(crb.i[i]);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      S6 cd = k < 3 ? S6{v3(0, 0, 0), v3(k == 0, k == 1, k == 2)} : s.cdr[k - 3];
+      S6 f = inert_mul(crb_base, cd);
+      float fl[3] = {f.l.x, f.l.y, f.l.z};
+#pragma unroll
+      for (int kk = 0; kk <= k; kk++) s.M.bb[tri(k, kk)] = kk < 3 ? fl[kk] : dot6(s.cdr[kk - 3], f);
+    }
+    s.LM = s.M;
+    qarrow_factor(s.LM);
+  }
+
+  PG_INL void velocity_stage() {
+    S6 cv0{v3(0, 0, 0), v3(s.vb[0], s.vb[1], s.vb[2])};
+#pragma unroll
+    for (int k = 0; k < 3; k++) s.cddr[k] = motion_cross(cv0, s.cdr[k]);
+    S6 cvb = cv0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) cvb = cvb + s.cdr[k] * s.vb[3 + k];
+    s.cvel0 = cvb;
+    S6 caccb{v3(0, 0, 0), v3(-m->gravity[0], -m->gravity[1], -m->gravity[2])};
+#pragma unroll
+    for (int k = 0; k < 3; k++) caccb = caccb + s.cddr[k] * s.vb[3 + k];
+    auto body_force = [&](const I10& ci, S6 cv, S6 cacc) {
+      S6 f1 = inert_mul(ci, cacc);
+      S6 f2 = inert_mul(ci, cv);
+      return f1 + motion_cross_force(cv, f2);
+    };
+    S6 cv = cvb, ca = caccb, fb[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      s.cddl[k] = motion_cross(cv, s.cdl[k]);
+      cv = cv + s.cdl[k] * s.vl[k];
+      s.cvell[k] = cv;
+      ca = ca + s.cddl[k] * s.vl[k];
+      fb[k] = body_force(s.cinl[k], cv, ca);
+    }
+    fb[1] = fb[1] + fb[2]; fb[0] = fb[0] + fb[1];
+    float bias_l[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) bias_l[k] = dot6(s.cdl[k], fb[k]);
+    S6 f0 = body_force(s.cin0, cvb, caccb);
+    S6 fbase{f0.a + quad_sum(fb[0].a), f0.l + quad_sum(fb[0].l)};
+    float bias_b[6] = {fbase.l.x, fbase.l.y, fbase.l.z, dot6(s.cdr[0], fbase), dot6(s.cdr[1], fbase), dot6(s.cdr[2], fbase)};
+#pragma unroll
+    for (int i = 0; i < 6; i++) s.qfs_b[i] = -m->dof_damping[i] * s.vb[i] - bias_b[i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int a = 3 * (l ^ 1) + k;
+      float c = fminf(fmaxf(s.ctrl[k], m->act_ctrlrange[a][0]), m->act_ctrlrange[a][1]);
+      float force = em.gain[k] * c + (m->act_bias[a][0] + em.bias1[k] * s.ql[k] + m->act_bias[a][2] * s.vl[k]);
+      force = fminf(fmaxf(force, m->act_forcerange[a][0]), m->act_forcerange[a][1]);
+      s.act_force[k] = force;
+      s.qfs_l[k] = -em.damping[k] * s.vl[k] - bias_l[k] + force;
+    }
+    qarrow_solve(s.LM, s.qfs_b, s.qfs_l, s.qas_b, s.qas_l);
+  }
+
+  PG_INL void contact_jac(QContact& c, V3 pos, V3 n, V3 t1, V3 t2, float sign) const {
+    V3 off = pos - s.com;
+    V3 fr[3] = {n * sign, t1 * sign, t2 * sign};
+    V3 col[9];
+    col[0] = v3(1, 0, 0); col[1] = v3(0, 1, 0); col[2] = v3(0, 0, 1);
+#pragma unroll
+    for (int k = 0; k < 3; k++) col[3 + k] = s.cdr[k].l + cross(s.cdr[k].a, off);
+#pragma unroll
+    for (int k = 0; k < 3; k++) col[6 + k] = s.cdl[k].l + cross(s.cdl[k].a, off);
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int k = 0; k < 9; k++) c.J[a][k] = dot(fr[a], col[k]);
+  }
+  PG_INL void finish_contact(QContact& c, const float* solref, const float* solimp, float includemargin, float invw_body) const {
+    float pos = c.dist - includemargin;
+    c.row_active = c.on && pos < 0.f;
+    float kimp, b, imp;
+    kbi(m->timestep, solref, solimp, pos, kimp, b, imp);
+    float mu = c.mu;
+    float invweight = (invw_body + mu * mu * invw_body) * 2.0f * mu * mu / m->impratio;
+    float r = fmaxf(invweight * (1.0f - imp) / imp, kMinVal);
+    c.D = c.row_active ? 1.0f / r : 0.f;
+    float t[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      float x = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; k++) x += c.J[a][k] * s.vb[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) x += c.J[a][6 + k] * s.vl[k];
+      t[a] = x;
+    }
+    float jv[4] = {t[0] + mu * t[1], t[0] - mu * t[1], t[0] + mu * t[2], t[0] - mu * t[2]};
+#pragma unroll
+    for (int r4 = 0; r4 < 4; r4++) c.aref[r4] = c.row_active ? (-b * jv[r4] - kimp * pos) : 0.f;
+  }
+  PG_INL void clear_contact(QContact& c) const {
+    c.on = false; c.row_active = false; c.box = -2; c.dist = 1.f; c.mu = 0.f; c.D = 0.f;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; r4++) c.aref[r4] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int k = 0; k < 9; k++) c.J[a][k] = 0.f;
+  }
+
+  PG_INL void constraint_stage(const TerrainBox* __restrict__ boxes, int nbox, const float* __restrict__ box_fr, int N, int e) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int j = 3 * l + k;
+      float q = s.ql[k];
+      float dmin = q - m->jnt_range[j][0], dmax = m->jnt_range[j][1] - q;
+      float pos = fminf(dmin, dmax);
+      bool act = pos < 0.f;
+      s.lim_active[k] = act;
+      s.lim_sign[k] = dmin < dmax ? 1.0f : -1.0f;
+      float kimp, b, imp;
+      kbi(m->timestep, m->jnt_solref, m->jnt_solimp, pos, kimp, b, imp);
+      float r = fmaxf(m->dof_invweight0[6 + j] * (1.0f - imp) / imp, kMinVal);
+      s.lim_D[k] = act ? 1.0f / r : 0.f;
+      s.lim_aref[k] = act ? (-b * (s.lim_sign[k] * s.vl[k]) - kimp * pos) : 0.f;
+    }
+    auto mix = [&](const float* sr1, const float* si1, float sm1, const float* sr2, const float* si2, float sm2, float* sr, float* si) {
+      float mixw = sm1 / (sm1 + sm2);
+      if (sm1 < kMinVal && sm2 < kMinVal) mixw = 0.5f; else if (sm1 < kMinVal) mixw = 0.f; else if (sm2 < kMinVal) mixw = 1.f;
+      if (sr1[0] > 0.f && sr2[0] > 0.f) { sr[0] = mixw * sr1[0] + (1 - mixw) * sr2[0]; sr[1] = mixw * sr1[1] + (1 - mixw) * sr2[1]; }
+      else { sr[0] = fminf(sr1[0], sr2[0]); sr[1] = fminf(sr1[1], sr2[1]); }
+#pragma unroll
+      for (int i = 0; i < 5; i++) si[i] = mixw * si1[i] + (1 - mixw) * si2[i];
+    };
+    const float invw_calf = m->body_invweight0[3 + 3 * l][0];
+    const float rad = m->foot_radius[l];
+    {   // own foot vs the plane
+      float sr[2], si[5];
+      mix(m->floor_solref, m->floor_solimp, m->floor_solmix, m->foot_solref, m->foot_solimp, m->foot_solmix, sr, si);
+      float margin = fmaxf(m->floor_margin, m->foot_margin) - fmaxf(m->floor_gap, m->foot_gap);
+      QContact& c = s.con[0];
+      c.on = true; c.box = -1; c.mu = fmaxf(em.floor_friction, m->foot_friction[0]);
+      c.dist = s.footc.z - rad;
+      V3 pos = s.footc - v3(0, 0, 1) * (rad + 0.5f * c.dist);
+      contact_jac(c, pos, v3(0, 0, 1), v3(0, 1, 0), v3(-1, 0, 0), 1.0f);
+      finish_contact(c, sr, si, margin, invw_calf);
+    }
+#pragma unroll
+    for (int k = 1; k <= kMaxB; k++) clear_contact(s.con[k]);
+    s.nbox = 0;
+    if (boxes == nullptr || nbox <= 0) return;
+    const int maxp = m->max_geom_pairs, maxc = m->max_contact_points;
+    const bool broad = maxp > -1 && 4 * nbox > maxp;
+    const float keyC = rad + m->box_rbound;
+    // pass 1: own foot against every box; penetrating pairs (narrow phase dist < 0) are kept
+    QPen pen[kMaxPenQ]; int npen = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxPenQ; i++) { pen[i].dist = 1.f; pen[i].key = 3.0e38f; pen[i].idx = 0x7fffffff; pen[i].pos = v3(0, 0, 0); pen[i].n = v3(0, 0, 1); }
+#pragma unroll 4
+    for (int b = 0; b < nbox; b++) {
+      const float4 A = reinterpret_cast<const float4*>(boxes + b)[0];
+      float dc = norm(v3(A.x, A.y, A.z) - s.footc);
+      if (dc <= A.w + rad + 1e-5f) {
+        TerrainBox tb = boxes[b];
+        float nd; V3 pw, nw;
+        sphere_box(s.footc, rad, tb, nd, pw, nw);
+        if (nd < 0.f && npen < kMaxPenQ) {
+          QPen pp; pp.dist = nd; pp.key = dc - keyC; pp.idx = l * nbox + b; pp.pos = pw; pp.n = nw;
+#pragma unroll
+          for (int i = 0; i < kMaxPenQ; i++) if (i == npen) pen[i] = pp;
+          npen++;
+        }
+      }
+    }
+    if (__ballot(npen > 0) == 0ull) return;
+    // candidate table of the whole quad (replicated): key/idx/dist of lane j's i-th penetrating pair
+    float ckey[4][kMaxPenQ], cdist[4][kMaxPenQ]; int cidx[4][kMaxPenQ], crank[4][kMaxPenQ];
+#pragma unroll
+    for (int i = 0; i < kMaxPenQ; i++) {
+      ckey[0][i] = quad_bcast<0>(pen[i].key); ckey[1][i] = quad_bcast<1>(pen[i].key); ckey[2][i] = quad_bcast<2>(pen[i].key); ckey[3][i] = quad_bcast<3>(pen[i].key);
+      cdist[0][i] = quad_bcast<0>(pen[i].dist); cdist[1][i] = quad_bcast<1>(pen[i].dist); cdist[2][i] = quad_bcast<2>(pen[i].dist); cdist[3][i] = quad_bcast<3>(pen[i].dist);
+      cidx[0][i] = quad_bcast<0>(pen[i].idx); cidx[1][i] = quad_bcast<1>(pen[i].idx); cidx[2][i] = quad_bcast<2>(pen[i].idx); cidx[3][i] = quad_bcast<3>(pen[i].idx);
+#pragma unroll
+      for (int j = 0; j < 4; j++) crank[j][i] = 0;
+    }
+    // wave-uniform number of candidate columns that are in use anywhere
+    int ncol = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxPenQ; i++) if (__ballot(npen > i) != 0ull) ncol = i + 1;
+    if (broad) {
+      // pass 2: exact broad-phase rank = number of the 400 (foot, box) pairs that sort before the candidate;
+      // every lane counts over its own foot's pairs, the quad sum gives the rank
+#pragma unroll 2
+      for (int b = 0; b < nbox; b++) {
+        const float4 A = reinterpret_cast<const float4*>(boxes + b)[0];
+        float key = norm(v3(A.x, A.y, A.z) - s.footc) - keyC;
+        int idx = l * nbox + b;
+#pragma unroll
+        for (int i = 0; i < kMaxPenQ; i++) {
+          if (i >= ncol) break;
+#pragma unroll
+          for (int j = 0; j < 4; j++) crank[j][i] += (key < ckey[j][i] || (key == ckey[j][i] && idx < cidx[j][i])) ? 1 : 0;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < kMaxPenQ; i++) {
+        if (i >= ncol) break;
+#pragma unroll
+        for (int j = 0; j < 4; j++) crank[j][i] = quad_sum_i(crank[j][i]);
+      }
+    }
+    // replicated selection of the max_contact_points deepest survivors (ties: lower broad-phase rank first)
+    bool taken[4][kMaxPenQ], mine[kMaxPenQ];
+#pragma unroll
+    for (int i = 0; i < kMaxPenQ; i++) {
+      mine[i] = false;
+#pragma unroll
+      for (int j = 0; j < 4; j++) taken[j][i] = !(cdist[j][i] < 0.f) || (broad && crank[j][i] >= maxp);
+    }
+    const int nslot = (maxc > -1 && maxc < 4) ? maxc : 4;
+    for (int k = 0; k < nslot; k++) {
+      int bj = -1, bi = -1; float bd = 0.f; int br = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < kMaxPenQ; i++) {
+          bool better = !taken[j][i] && (bj < 0 || cdist[j][i] < bd || (cdist[j][i] == bd && crank[j][i] < br));
+          if (better) { bj = j; bi = i; bd = cdist[j][i]; br = crank[j][i]; }
+        }
+      if (__ballot(bj >= 0) == 0ull) break;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < kMaxPenQ; i++) if (j == bj && i == bi) { taken[j][i] = true; if (j == l) mine[i] = true; }
+    }
+    // own selected pairs become own box contacts
+    float sr[2], si[5];
+    mix(m->foot_solref, m->foot_solimp, m->foot_solmix, m->box_solref, m->box_solimp, m->box_solmix, sr, si);
+    float margin = fmaxf(m->foot_margin, m->box_margin) - fmaxf(m->foot_gap, m->box_gap);
+    int nb = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxPenQ; i++) {
+      if (i >= ncol) break;
+      if (mine[i]) {
+        QContact cc;
+        cc.on = true; cc.dist = pen[i].dist;
+        int b = pen[i].idx - l * nbox;
+        cc.box = b;
+        float bf = box_fr ? box_fr[(long)b * N + e] : m->box_friction[0];
+        cc.mu = fmaxf(bf, m->foot_friction[0]);
+        V3 n, t1, t2;
+        make_frame(pen[i].n, n, t1, t2);
+        contact_jac(cc, pen[i].pos, n, t1, t2, -1.0f);
+        finish_contact(cc, sr, si, margin, invw_calf);
+#pragma unroll
+        for (int k = 0; k < kMaxB; k++) if (k == nb) s.con[1 + k] = cc;
+        nb++;
+      }
+    }
+    s.nbox = nb;
+  }
+};
+
+// ------------------------------------------------------------------ Newton solver, quad version
+struct QSolver {
+  const PgttModel* __restrict__ m;
+  QSim& s;
+  float qb[6], ql[3], Mab[6], Mal[3], gb[6], gl[3], sb[6], sl[3], fcb[6], fcl[3];
+  float jar_lim[3], jar_con[1 + kMaxB][4];
+  float gauss, cost, prev_cost;
+  int nslots;     // wave-uniform number of own-box-contact slots in use anywhere in the wave
+
+  PG_INL QSolver(const PgttModel* m_, QSim& s_) : m(m_), s(s_) {}
+
+  PG_INL void con_jx(const QContact& c, const float* xb, const float* xl, float* out4) const {
+    float t[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; k++) v += c.J[a][k] * xb[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) v += c.J[a][6 + k] * xl[k];
+      t[a] = v;
+    }
+    out4[0] = t[0] + c.mu * t[1]; out4[1] = t[0] - c.mu * t[1]; out4[2] = t[0] + c.mu * t[2]; out4[3] = t[0] - c.mu * t[2];
+  }
+
+  PG_INL void init(const float* q0b, const float* q0l) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) qb[i] = q0b[i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) ql[k] = q0l[k];
+    qarrow_mul(s.M, qb, ql, Mab, Mal);
+#pragma unroll
+    for (int k = 0; k < 3; k++) jar_lim[k] = s.lim_sign[k] * ql[k] * (s.lim_active[k] ? 1.f : 0.f) - s.lim_aref[k];
+#pragma unroll
+    for (int c = 0; c <= kMaxB; c++) {
+      if (c > nslots) break;
+      float jx[4];
+      con_jx(s.con[c], qb, ql, jx);
+#pragma unroll
+      for (int r = 0; r < 4; r++) jar_con[c][r] = (s.con[c].row_active ? jx[r] : 0.f) - s.con[c].aref[r];
+    }
+    cost = INFINITY; prev_cost = 0.f;
+  }
+
+  PG_INL void update_constraint() {
+    float csum = 0.f, pb[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) pb[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      float ja = jar_lim[k];
+      float f = ja < 0.f ? -s.lim_D[k] * ja : 0.f;
+      fcl[k] = s.lim_sign[k] * f;
+      csum += ja < 0.f ? s.lim_D[k] * ja * ja : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c <= kMaxB; c++) {
+      if (c > nslots) break;
+      const QContact& cn = s.con[c];
+      float f[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float ja = jar_con[c][r];
+        f[r] = ja < 0.f ? -cn.D * ja : 0.f;
+        csum += ja < 0.f ? cn.D * ja * ja : 0.f;
+      }
+      float g[3] = {f[0] + f[1] + f[2] + f[3], cn.mu * (f[0] - f[1]), cn.mu * (f[2] - f[3])};
+#pragma unroll
+      for (int k = 0; k < 6; k++) pb[k] += cn.J[0][k] * g[0] + cn.J[1][k] * g[1] + cn.J[2][k] * g[2];
+#pragma unroll
+      for (int k = 0; k < 3; k++) fcl[k] += cn.J[0][6 + k] * g[0] + cn.J[1][6 + k] * g[1] + cn.J[2][6 + k] * g[2];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) fcb[i] = quad_sum(pb[i]);
+    float gbase = 0.f, gleg = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; i++) gbase += (Mab[i] - s.qfs_b[i]) * (qb[i] - s.qas_b[i]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) gleg += (Mal[k] - s.qfs_l[k]) * (ql[k] - s.qas_l[k]);
+    gauss = 0.5f * (gbase + quad_sum(gleg));
+    prev_cost = cost;
+    cost = 0.5f * quad_sum(csum) + gauss;
+  }
+
+  PG_INL void update_gradient() {
+#pragma unroll
+    for (int i = 0; i < 6; i++) gb[i] = Mab[i] - s.qfs_b[i] - fcb[i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) gl[k] = Mal[k] - s.qfs_l[k] - fcl[k];
+    QArrow H;
+    float Gbb[21];
+#pragma unroll
+    for (int i = 0; i < 21; i++) Gbb[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 18; i++) H.lb[i] = s.M.lb[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) H.ll[i] = s.M.ll[i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) H.ll[tri(k, k)] += jar_lim[k] < 0.f ? s.lim_D[k] : 0.f;
+#pragma unroll
+    for (int c = 0; c <= kMaxB; c++) {
+      if (c > nslots) break;
+      const QContact& cn = s.con[c];
+      float w[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) w[r] = jar_con[c][r] < 0.f ? cn.D : 0.f;
+      float mu = cn.mu;
+      float W00 = w[0] + w[1] + w[2] + w[3], W01 = mu * (w[0] - w[1]), W02 = mu * (w[2] - w[3]);
+      float W11 = mu * mu * (w[0] + w[1]), W22 = mu * mu * (w[2] + w[3]);
+      float T[3][9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        T[0][k] = W00 * cn.J[0][k] + W01 * cn.J[1][k] + W02 * cn.J[2][k];
+        T[1][k] = W01 * cn.J[0][k] + W11 * cn.J[1][k];
+        T[2][k] = W02 * cn.J[0][k] + W22 * cn.J[2][k];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) Gbb[tri(i, j)] += cn.J[0][i] * T[0][j] + cn.J[1][i] * T[1][j] + cn.J[2][i] * T[2][j];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) H.lb[i * 6 + k] += cn.J[0][6 + i] * T[0][k] + cn.J[1][6 + i] * T[1][k] + cn.J[2][6 + i] * T[2][k];
+#pragma unroll
+        for (int j = 0; j <= i; j++) H.ll[tri(i, j)] += cn.J[0][6 + i] * T[0][6 + j] + cn.J[1][6 + i] * T[1][6 + j] + cn.J[2][6 + i] * T[2][6 + j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 21; i++) H.bb[i] = s.M.bb[i] + quad_sum(Gbb[i]);
+    qarrow_factor(H);
+    float mgb[6], mgl[3];
+    qarrow_solve(H, gb, gl, mgb, mgl);
+#pragma unroll
+    for (int i = 0; i < 6; i++) sb[i] = -mgb[i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) sl[k] = -mgl[k];
+  }
+
+  struct LSPoint { float alpha, cost, d0, d1; };
+
+  PG_INL void linesearch(bool frozen) {
+    float snb = 0.f, snl = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; i++) snb += sb[i] * sb[i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) snl += sl[k] * sl[k];
+    float smag = sqrtf(snb + quad_sum(snl)) * m->meaninertia * 18.0f;
+    float gtol = m->tolerance * m->ls_tolerance * smag;
+    float mvb[6], mvl[3];
+    qarrow_mul(s.M, sb, sl, mvb, mvl);
+    float jv_lim[3], jv_con[1 + kMaxB][4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) jv_lim[k] = s.lim_active[k] ? s.lim_sign[k] * sl[k] : 0.f;
+#pragma unroll
+    for (int c = 0; c <= kMaxB; c++) {
+      if (c > nslots) break;
+      float jx[4];
+      con_jx(s.con[c], sb, sl, jx);
+#pragma unroll
+      for (int r = 0; r < 4; r++) jv_con[c][r] = s.con[c].row_active ? jx[r] : 0.f;
+    }
+    float ab = 0.f, bb_ = 0.f, eb = 0.f, al = 0.f, bl = 0.f, el = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { ab += sb[i] * Mab[i]; bb_ += sb[i] * s.qfs_b[i]; eb += sb[i] * mvb[i]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { al += sl[k] * Mal[k]; bl += sl[k] * s.qfs_l[k]; el += sl[k] * mvl[k]; }
+    const float qg0 = gauss, qg1 = (ab + quad_sum(al)) - (bb_ + quad_sum(bl)), qg2 = 0.5f * (eb + quad_sum(el));
+    auto point = [&](float alpha) {
+      float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        float x = jar_lim[k] + alpha * jv_lim[k];
+        float d = x < 0.f ? s.lim_D[k] : 0.f;
+        q0 += d * (0.5f * jar_lim[k] * jar_lim[k]); q1 += d * (jv_lim[k] * jar_lim[k]); q2 += d * (0.5f * jv_lim[k] * jv_lim[k]);
+      }
+#pragma unroll
+      for (int c = 0; c <= kMaxB; c++) {
+        if (c > nslots) break;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          float ja = jar_con[c][r], jv = jv_con[c][r];
+          float x = ja + alpha * jv;
+          float d = x < 0.f ? s.con[c].D : 0.f;
+          q0 += d * (0.5f * ja * ja); q1 += d * (jv * ja); q2 += d * (0.5f * jv * jv);
+        }
+      }
+      q0 = quad_sum(q0) + qg0; q1 = quad_sum(q1) + qg1; q2 = quad_sum(q2) + qg2;
+      LSPoint p;
+      p.alpha = alpha;
+      p.cost = alpha * alpha * q2 + alpha * q1 + q0;
+      p.d0 = 2.0f * alpha * q2 + q1;
+      p.d1 = 2.0f * q2 + (q2 == 0.f ? kMinVal : 0.f);
+      return p;
+    };
+    auto in_bracket = [](const LSPoint& x, const LSPoint& y) {
+      return ((x.d0 < y.d0) && (y.d0 < 0.f)) || ((x.d0 > y.d0) && (y.d0 > 0.f));
+    };
+    LSPoint p0 = point(0.f);
+    LSPoint lo0 = point(p0.alpha - p0.d0 / p0.d1);
+    bool lesser = lo0.d0 < p0.d0;
+    LSPoint hi = lesser ? p0 : lo0, lo = lesser ? lo0 : p0;
+    bool swap = true; int it = 0;
+    for (;;) {
+      bool done = it >= m->ls_iterations || !swap || ((lo.d0 < 0.f) && (lo.d0 > -gtol)) || ((hi.d0 > 0.f) && (hi.d0 < gtol));
+      if (__ballot(!done) == 0ull) break;
+      float al3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha)};
+      LSPoint pt[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) pt[k] = point(al3[k]);
+      LSPoint nlo = lo, nhi = hi;
+      bool s1 = in_bracket(nlo, pt[0]); if (s1) nlo = pt[0];
+      bool s2 = in_bracket(nlo, pt[2]); if (s2) nlo = pt[2];
+      bool s3 = in_bracket(nlo, pt[1]); if (s3) nlo = pt[1];
+      bool t1 = in_bracket(nhi, pt[1]); if (t1) nhi = pt[1];
+      bool t2 = in_bracket(nhi, pt[2]); if (t2) nhi = pt[2];
+      bool t3 = in_bracket(nhi, pt[0]); if (t3) nhi = pt[0];
+      if (!done) { lo = nlo; hi = nhi; swap = s1 | s2 | s3 | t1 | t2 | t3; it++; }
+    }
+    bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
+    float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+    float ia = (improved && !frozen) ? alpha : 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { qb[i] += sb[i] * ia; Mab[i] += mvb[i] * ia; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { ql[k] += sl[k] * ia; Mal[k] += mvl[k] * ia; jar_lim[k] += jv_lim[k] * ia; }
+#pragma unroll
+    for (int c = 0; c <= kMaxB; c++) {
+      if (c > nslots) break;
+#pragma unroll
+      for (int r = 0; r < 4; r++) jar_con[c][r] += jv_con[c][r] * ia;
+    }
+  }
+
+  PG_INL void solve() {
+    int nb = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxB; k++) if (__ballot(s.nbox > k) != 0ull) nb = k + 1;
+    nslots = nb;
+    init(s.wb, s.wl); update_constraint();
+    float cw = cost;
+    init(s.qas_b, s.qas_l); update_constraint();
+    if (__ballot(cw < cost) != 0ull) {
+      // warm start wins in at least one env of the wave: evaluate it for everybody, keep per env
+      float kb[6], kl[3];
+      const bool usew = cw < cost;
+#pragma unroll
+      for (int i = 0; i < 6; i++) kb[i] = usew ? s.wb[i] : s.qas_b[i];
+#pragma unroll
+      for (int k = 0; k < 3; k++) kl[k] = usew ? s.wl[k] : s.qas_l[k];
+      init(kb, kl); update_constraint();
+    }
+    update_gradient();
+    const float scale = m->meaninertia * 18.0f;
+    int niter = 0;
+    for (;;) {
+      float gnb = 0.f, gnl = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; i++) gnb += gb[i] * gb[i];
+#pragma unroll
+      for (int k = 0; k < 3; k++) gnl += gl[k] * gl[k];
+      float gn = gnb + quad_sum(gnl);
+      bool done = niter >= m->iterations || ((prev_cost - cost) / scale < m->tolerance) || (sqrtf(gn) / scale < m->tolerance);
+      if (__ballot(!done) == 0ull) break;
+      linesearch(done);
+      update_constraint();
+      update_gradient();
+      if (!done) niter++;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) { s.qacc_b[i] = qb[i]; s.wb[i] = qb[i]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { s.qacc_l[k] = ql[k]; s.wl[k] = ql[k]; }
+    s.niter = niter; s.niter_max = niter > s.niter_max ? niter : s.niter_max;
+  }
+};
+
+}  // namespace pgtt

@@ -120,7 +120,9 @@ def run_parity(task, n, terrain, steps, dr=False, autoreset=False, noise=1.0):
         eg = per_env_errors(g, hb)
         ef = per_env_errors(hb.arrays, h64)
         EG.append(eg); EF.append(ef)
-        well = (g["dbg_niter"] < 5) & (hb["dbg_niter"] < 5) & (h64["dbg_niter"] < 5)
+        # converged everywhere AND the oracle's own fp32 / fp64 builds agree (a line search that stalls on fp32
+        # rounding also "converges", to a different point: such env-steps are ill-posed in fp32 for everybody)
+        well = (g["dbg_niter"] < 5) & (hb["dbg_niter"] < 5) & (h64["dbg_niter"] < 5) & (ef["qpos"] < 1e-5) & (ef["qvel"] < 1e-3)
         well_total += int(well.sum())
         # integers never depend on the solver path
         assert np.array_equal(g["istate"], hb["istate"]), k
