@@ -159,6 +159,10 @@ int pgtt_set_terrain(pgtt_handle h, const float* boxes, int T, int B) {
     volatile float c1 = b0 - q22; t.m22 = c1 + q33;
     t.sx = r[7]; t.sy = r[8]; t.sz = r[9];
     t.rb = std::sqrt(r[7] * r[7] + r[8] * r[8] + r[9] * r[9]) * 1.000001f;
+    t.hx = (std::fabs(t.m00) * r[7] + std::fabs(t.m01) * r[8] + std::fabs(t.m02) * r[9]) * 1.00001f + 1e-6f;
+    t.hy = (std::fabs(t.m10) * r[7] + std::fabs(t.m11) * r[8] + std::fabs(t.m12) * r[9]) * 1.00001f + 1e-6f;
+    t.hz = (std::fabs(t.m20) * r[7] + std::fabs(t.m21) * r[8] + std::fabs(t.m22) * r[9]) * 1.00001f + 1e-6f;
+    t.pad = 0.f;
   }
   HIP_TRY(hipMalloc(&h->d_terrain, tab.size() * sizeof(pgtt::TerrainBox)));
   HIP_TRY(hipMemcpy(h->d_terrain, tab.data(), tab.size() * sizeof(pgtt::TerrainBox), hipMemcpyHostToDevice));

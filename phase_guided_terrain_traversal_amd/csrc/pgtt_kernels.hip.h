@@ -86,20 +86,34 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   }
   const TerrainBox* boxes = nullptr;
   int nbox = 0;
+  // LDS staging of the env's terrain variant: centre + bounding radius of its <=100 boxes (read 2 x 4 substeps
+  // by the broad phase), and a per-lane column for the broad-phase keys of the own foot
+  __shared__ float4 sh_box[HAS_TERRAIN ? PGTT_MAX_BOX * 16 : 1];      // (cx, cy, cz, hx)
+  __shared__ float2 sh_box2[HAS_TERRAIN ? PGTT_MAX_BOX * 16 : 1];     // (hy, hz)
+  __shared__ int sh_cand[HAS_TERRAIN ? kMaxCand * 64 : 1];
+  __shared__ float sh_con[HAS_TERRAIN ? kMaxB * kSlotFields * 64 : 1];
+  const int quad = threadIdx.x >> 2;
+  const BoxSlots slots{sh_con, (int)threadIdx.x};
   if (HAS_TERRAIN) {
     int v = a.buf.variant ? a.buf.variant[e] : 0;
     boxes = a.terrain + (long)v * a.B;
     nbox = a.B;
+    for (int b = l; b < nbox; b += 4) {
+      const TerrainBox* tb = boxes + b;
+      sh_box[b * 16 + quad] = make_float4(tb->px, tb->py, tb->pz, tb->hx);
+      sh_box2[b * 16 + quad] = make_float2(tb->hy, tb->hz);
+    }
+    __syncthreads();
   }
   s.niter = 0; s.niter_max = 0;
   QPhysics ph(m, em, s, l);
-  QSolver sol(m, s);
+  QSolver sol(m, s, slots);
   const int nsub = MODE == MODE_STEP ? cfg->n_substeps : 1;
   const float dt = m->timestep;
   for (int sub = 0; sub < nsub; sub++) {
     ph.position_stage();
     ph.velocity_stage();
-    ph.constraint_stage(boxes, nbox, a.buf.box_friction, N, e);
+    ph.constraint_stage(boxes, nbox, a.buf.box_friction, N, e, sh_box, sh_box2, sh_cand, slots, quad);
     // ---- sensors of the last forward (pre-integration state), written BEFORE the solve; the accelerometer is
     //      kept as an affine map of qacc[0:6]
     float accA[3][6], acc0[3];
@@ -131,9 +145,11 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
       }
       // own foot: sensor order FR,FL,RR,RL = leg ^ 1
       const int f = l ^ 1;
-      bool touching = false;
+      bool touching = s.con0.dist < 0.f;
+      if (HAS_TERRAIN) {
 #pragma unroll
-      for (int c = 0; c <= kMaxB; c++) touching = touching || (s.con[c].on && s.con[c].dist < 0.f);
+        for (int k = 0; k < kMaxB; k++) touching = touching || (k < s.nbox && slots.at(k, 0) < 0.f);
+      }
       // box-contact slot numbering of the debug record: own contacts follow those of the lower legs
       const int n0 = quad_bcast<0>(s.nbox), n1 = quad_bcast<1>(s.nbox), n2 = quad_bcast<2>(s.nbox), n3 = quad_bcast<3>(s.nbox);
       const int off = l == 0 ? 0 : (l == 1 ? n0 : (l == 2 ? n0 + n1 : n0 + n1 + n2)), total = n0 + n1 + n2 + n3;
@@ -147,9 +163,12 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
         for (int k = 0; k < 3; k++) Fr[(PGTT_F_ACT_FORCE + 3 * f + k) * (long)N + e] = s.act_force[k];
         if (a.buf.dbg_contact && a.buf.dbg_dist) {
           int* dc = a.buf.dbg_contact + (long)e * 16; float* dd = a.buf.dbg_dist + (long)e * 8;
-          dc[2 * l] = l; dc[2 * l + 1] = -1; dd[l] = s.con[0].dist;
+          dc[2 * l] = l; dc[2 * l + 1] = -1; dd[l] = s.con0.dist;
+          if (HAS_TERRAIN) {
 #pragma unroll
-          for (int k = 0; k < kMaxB; k++) if (k < s.nbox && off + k < 4) { dc[2 * (4 + off + k)] = l; dc[2 * (4 + off + k) + 1] = s.con[1 + k].box; dd[4 + off + k] = s.con[1 + k].dist; }
+            for (int k = 0; k < kMaxB; k++) if (k < s.nbox && off + k < 4) {
+              dc[2 * (4 + off + k)] = l; dc[2 * (4 + off + k) + 1] = __float_as_int(slots.at(k, 20)); dd[4 + off + k] = slots.at(k, 0); }
+          }
           if (l == 0) {
 #pragma unroll
             for (int k = 0; k < 4; k++) if (k >= total) { dc[2 * (4 + k)] = -1; dc[2 * (4 + k) + 1] = -2; dd[4 + k] = 1.0f; }

@@ -24,11 +24,12 @@ constexpr float kMinImp = 0.0001f;
 constexpr float kMaxImp = 0.9999f;
 constexpr int kMaxPen = 8;          // per-env cap on simultaneously penetrating (foot, box) pairs
 
-struct TerrainBox {                 // resident terrain table entry (64 B), built once by pgtt_set_terrain
+struct TerrainBox {                 // resident terrain table entry (80 B), built once by pgtt_set_terrain
   float px, py, pz, rb;             // centre, bounding radius |half-size|
   float sx, sy, sz, m00;            // half-size, rotation matrix row-major
   float m01, m02, m10, m11;
   float m12, m20, m21, m22;
+  float hx, hy, hz, pad;            // half-extents of the WORLD-axis-aligned bounding box (|R| size, rounded up)
 };
 
 // ------------------------------------------------------------------ small vector helpers
@@ -299,38 +300,38 @@ PG_INL void sphere_box(V3 c_world, float radius, const TerrainBox& tb, float& di
   M3 R; R.m[0] = tb.m00; R.m[1] = tb.m01; R.m[2] = tb.m02; R.m[3] = tb.m10; R.m[4] = tb.m11; R.m[5] = tb.m12;
   R.m[6] = tb.m20; R.m[7] = tb.m21; R.m[8] = tb.m22;
   V3 c = mtmul(R, c_world - v3(tb.px, tb.py, tb.pz));
-  float cc[3] = {c.x, c.y, c.z}, sz[3] = {tb.sx, tb.sy, tb.sz};
+  auto pick3 = [](int i, float x, float y, float z) { return i == 0 ? x : (i == 1 ? y : z); };
   const int fax[6] = {1, 2, 0, 1, 2, 0};
   const float fsg[6] = {-1.f, -1.f, 1.f, 1.f, 1.f, -1.f};
+  const float ccs[3] = {c.x, c.y, c.z}, szs[3] = {tb.sx, tb.sy, tb.sz};
   // support_f = dot((c - r n) - v0, n) = sg*c[ax] - r - size[ax]
   int best = 0; float bs = -3.0e38f;
 #pragma unroll
   for (int f = 0; f < 6; f++) {
-    float s = fsg[f] * (cc[fax[f]] - fsg[f] * radius - fsg[f] * sz[fax[f]]);
+    float s = fsg[f] * (ccs[fax[f]] - fsg[f] * radius - fsg[f] * szs[fax[f]]);
     if (s >= 0.f) s = -1e12f;
     if (s > bs) { bs = s; best = f; }
   }
-  int ax = fax[best]; float sg = fsg[best];
-  // in-plane axes (u, v) and face vertex cycle, from the MJX vertex/face tables
-  //  face: v0 v1 v2 v3 as (sign_u, sign_v) patterns in the box's own axes; see table below
-  int au, av; float s0u, s0v, s1u, s1v, s2u, s2v, s3u, s3v;
-  switch (best) {
-    case 0: au = 0; av = 2; s0u = -1; s0v = -1; s1u = 1; s1v = -1; s2u = 1; s2v = 1; s3u = -1; s3v = 1; break;   // 0,4,5,1 (x,z)
-    case 1: au = 0; av = 1; s0u = -1; s0v = -1; s1u = -1; s1v = 1; s2u = 1; s2v = 1; s3u = 1; s3v = -1; break;   // 0,2,6,4 (x,y)
-    case 2: au = 1; av = 2; s0u = 1; s0v = -1; s1u = 1; s1v = 1; s2u = -1; s2v = 1; s3u = -1; s3v = -1; break;   // 6,7,5,4 (y,z)
-    case 3: au = 0; av = 2; s0u = -1; s0v = -1; s1u = -1; s1v = 1; s2u = 1; s2v = 1; s3u = 1; s3v = -1; break;   // 2,3,7,6 (x,z)
-    case 4: au = 0; av = 1; s0u = -1; s0v = -1; s1u = 1; s1v = -1; s2u = 1; s2v = 1; s3u = -1; s3v = 1; break;   // 1,5,7,3 (x,y)
-    default: au = 1; av = 2; s0u = -1; s0v = -1; s1u = -1; s1v = 1; s2u = 1; s2v = 1; s3u = 1; s3v = -1; break;  // 0,1,3,2 (y,z)
-  }
-  float su = sz[au], sv = sz[av];
+  // face axis, in-plane axes (u, v) and the vertex cycle of the chosen face (MJX vertex / face tables)
+  const int ax = best == 0 || best == 3 ? 1 : (best == 1 || best == 4 ? 2 : 0);
+  const float sg = (best == 2 || best == 3 || best == 4) ? 1.f : -1.f;
+  const int au = (best == 2 || best == 5) ? 1 : 0;
+  const int av = (best == 1 || best == 4) ? 1 : 2;
+  // vertex sign patterns: A = (-,-),(+,-),(+,+),(-,+) [faces 0,4]; B = (-,-),(-,+),(+,+),(+,-) [faces 1,3,5];
+  // C = (+,-),(+,+),(-,+),(-,-) [face 2]
+  const bool patA = best == 0 || best == 4, patC = best == 2;
+  const float s0u = patC ? 1.f : -1.f, s0v = -1.f;
+  const float s1u = patA ? 1.f : (patC ? 1.f : -1.f), s1v = patA ? -1.f : 1.f;
+  const float s2u = patC ? -1.f : 1.f, s2v = 1.f;
+  const float s3u = patA ? -1.f : (patC ? -1.f : 1.f), s3v = patA ? 1.f : -1.f;
+  const float su = pick3(au, tb.sx, tb.sy, tb.sz), sv = pick3(av, tb.sx, tb.sy, tb.sz), sw = pick3(ax, tb.sx, tb.sy, tb.sz);
+  const float cu = pick3(au, c.x, c.y, c.z), cvv = pick3(av, c.x, c.y, c.z), cw = pick3(ax, c.x, c.y, c.z);
   float fu[4] = {s0u * su, s1u * su, s2u * su, s3u * su}, fv[4] = {s0v * sv, s1v * sv, s2v * sv, s3v * sv};
   // project the centre onto the face plane: pt = c - ((c - v0).n) n   (n = sg * e_ax)
-  float dd = (cc[ax] - sg * sz[ax]) * sg;
-  float pt[3] = {cc[0], cc[1], cc[2]};
-  pt[ax] = cc[ax] - dd * sg;
-  float pu = pt[au], pv = pt[av];
+  float dd = (cw - sg * sw) * sg;
+  float pw = cw - dd * sg;
+  float pu = cu, pv = cvv;
   // edge k runs p0 = face[k-1] -> p1 = face[k]; edge normal = cross(p1 - p0, n) (NOT normalised, as in MJX)
-  // with e = (eu, ev) in (u,v) and n along ax: cross components in the (u,v) plane = sg' * (ev, -eu) up to the handedness of (au,av,ax)
   float hand = ((au + 1) % 3 == av) ? 1.0f : -1.0f;    // (au, av, ax) right-handed?
   float ed[4]; bool inside = true;
   float enu[4], env[4];
@@ -338,7 +339,6 @@ PG_INL void sphere_box(V3 c_world, float radius, const TerrainBox& tb, float& di
   for (int k = 0; k < 4; k++) {
     int k0 = (k + 3) & 3;
     float eu = fu[k] - fu[k0], ev = fv[k] - fv[k0];
-    // cross((eu,ev,0),(0,0,sg)) in a right-handed (u,v,w) basis = (ev*sg, -eu*sg, 0); flip if left-handed
     enu[k] = hand * ev * sg; env[k] = -hand * eu * sg;
     ed[k] = (pu - fu[k0]) * enu[k] + (pv - fv[k0]) * env[k];
     if (!(ed[k] <= 0.f)) inside = false;
@@ -356,7 +356,11 @@ PG_INL void sphere_box(V3 c_world, float radius, const TerrainBox& tb, float& di
   float abu = bu0 - au0, abv = bv0 - av0;
   float t = ((pu - au0) * abu + (pv - av0) * abv) / (abu * abu + abv * abv + 1e-6f);
   t = fminf(fmaxf(t, 0.f), 1.f);
-  if (!inside) { pt[au] = au0 + t * abu; pt[av] = av0 + t * abv; }
+  if (!inside) { pu = au0 + t * abu; pv = av0 + t * abv; }
+  // back from (u, v, w) to (x, y, z)
+  float pt[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) pt[i] = i == au ? pu : (i == av ? pv : pw);
   V3 ptv = v3(pt[0], pt[1], pt[2]);
   V3 n = ptv - c;
   float dn = normalize3(n);

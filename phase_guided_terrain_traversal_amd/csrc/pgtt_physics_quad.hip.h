@@ -31,6 +31,7 @@ template <int J> PG_INL int quad_bcast(int x) { return dpp_i<J * 0x55>(x); }
 
 constexpr int kMaxB = 4;          // box contacts one foot can hold (= max_contact_points of the reference)
 constexpr int kMaxPenQ = 4;       // penetrating (foot, box) pairs tracked per foot
+constexpr int kMaxCand = 16;      // boxes whose world AABB (+ foot radius) contains the foot centre, per foot
 
 struct QArrow { float bb[21]; float lb[18]; float ll[6]; };
 
@@ -40,7 +41,44 @@ struct QContact {
   int box;            // -1 plane, else box index
   float dist, mu, D;
   float aref[4];
-  float J[3][9];
+  V3 off;             // contact point relative to the robot COM
+  V3 fr[3];           // contact frame rows (normal, tangent1, tangent2), already multiplied by the body sign
+};
+// A contact Jacobian row is fr[a] . (V + W x off) where (W, V) is the calf's spatial motion: J itself (3x9) is
+// never stored; J x, J^T f and J^T W J are formed from (off, fr) and the leg's cdofs.
+
+// Box-contact records of the own foot live in LDS, one column per lane: field f of slot k at
+// sh[(k*kSlotFields + f)*64 + lane] (bank = lane: conflict-free).  This keeps the Newton loop's register
+// footprint independent of the number of box slots and lets the slot loops be real (wave-uniform) loops.
+constexpr int kSlotFields = 29;   // dist mu D aref[4] off[3] fr[9] flags box | jar[4] jv[4]
+struct BoxSlots {
+  float* sh; int lane;
+  PG_INL float& at(int k, int f) const { return sh[(k * kSlotFields + f) * 64 + lane]; }
+  PG_INL void store(int k, const QContact& c) const {
+    at(k, 0) = c.dist; at(k, 1) = c.mu; at(k, 2) = c.D;
+#pragma unroll
+    for (int r = 0; r < 4; r++) at(k, 3 + r) = c.aref[r];
+    at(k, 7) = c.off.x; at(k, 8) = c.off.y; at(k, 9) = c.off.z;
+#pragma unroll
+    for (int a = 0; a < 3; a++) { at(k, 10 + 3 * a) = c.fr[a].x; at(k, 11 + 3 * a) = c.fr[a].y; at(k, 12 + 3 * a) = c.fr[a].z; }
+    at(k, 19) = __int_as_float((c.on ? 1 : 0) | (c.row_active ? 2 : 0));
+    at(k, 20) = __int_as_float(c.box);
+  }
+  PG_INL QContact load(int k) const {
+    QContact c;
+    c.dist = at(k, 0); c.mu = at(k, 1); c.D = at(k, 2);
+#pragma unroll
+    for (int r = 0; r < 4; r++) c.aref[r] = at(k, 3 + r);
+    c.off = v3(at(k, 7), at(k, 8), at(k, 9));
+#pragma unroll
+    for (int a = 0; a < 3; a++) c.fr[a] = v3(at(k, 10 + 3 * a), at(k, 11 + 3 * a), at(k, 12 + 3 * a));
+    int fl = __float_as_int(at(k, 19));
+    c.on = (fl & 1) != 0; c.row_active = (fl & 2) != 0;
+    c.box = __float_as_int(at(k, 20));
+    return c;
+  }
+  PG_INL float& jar(int k, int r) const { return at(k, 21 + r); }
+  PG_INL float& jv(int k, int r) const { return at(k, 25 + r); }
 };
 
 struct QSim {
@@ -59,8 +97,8 @@ struct QSim {
   float qfs_b[6], qfs_l[3], qas_b[6], qas_l[3], act_force[3];
   // constraints
   bool lim_active[3]; float lim_sign[3], lim_D[3], lim_aref[3];
-  QContact con[1 + kMaxB];
-  int nbox;
+  QContact con0;             // own foot vs the plane (registers)
+  int nbox;                  // own box contacts; their records live in LDS (see BoxSlots)
   // outputs
   float qacc_b[6], qacc_l[3];
   int niter, niter_max;
@@ -335,18 +373,8 @@ struct QPhysics {
   }
 
   PG_INL void contact_jac(QContact& c, V3 pos, V3 n, V3 t1, V3 t2, float sign) const {
-    V3 off = pos - s.com;
-    V3 fr[3] = {n * sign, t1 * sign, t2 * sign};
-    V3 col[9];
-    col[0] = v3(1, 0, 0); col[1] = v3(0, 1, 0); col[2] = v3(0, 0, 1);
-#pragma unroll
-    for (int k = 0; k < 3; k++) col[3 + k] = s.cdr[k].l + cross(s.cdr[k].a, off);
-#pragma unroll
-    for (int k = 0; k < 3; k++) col[6 + k] = s.cdl[k].l + cross(s.cdl[k].a, off);
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int k = 0; k < 9; k++) c.J[a][k] = dot(fr[a], col[k]);
+    c.off = pos - s.com;
+    c.fr[0] = n * sign; c.fr[1] = t1 * sign; c.fr[2] = t2 * sign;
   }
   PG_INL void finish_contact(QContact& c, const float* solref, const float* solimp, float includemargin, float invw_body) const {
     float pos = c.dist - includemargin;
@@ -357,16 +385,9 @@ struct QPhysics {
     float invweight = (invw_body + mu * mu * invw_body) * 2.0f * mu * mu / m->impratio;
     float r = fmaxf(invweight * (1.0f - imp) / imp, kMinVal);
     c.D = c.row_active ? 1.0f / r : 0.f;
-    float t[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      float x = 0.f;
-#pragma unroll
-      for (int k = 0; k < 6; k++) x += c.J[a][k] * s.vb[k];
-#pragma unroll
-      for (int k = 0; k < 3; k++) x += c.J[a][6 + k] * s.vl[k];
-      t[a] = x;
-    }
+    // J qvel = frame . (velocity of the contact point) ; the calf's spatial velocity is cvell[2]
+    V3 vp = s.cvell[2].l + cross(s.cvell[2].a, c.off);
+    float t[3] = {dot(c.fr[0], vp), dot(c.fr[1], vp), dot(c.fr[2], vp)};
     float jv[4] = {t[0] + mu * t[1], t[0] - mu * t[1], t[0] + mu * t[2], t[0] - mu * t[2]};
 #pragma unroll
     for (int r4 = 0; r4 < 4; r4++) c.aref[r4] = c.row_active ? (-b * jv[r4] - kimp * pos) : 0.f;
@@ -375,13 +396,13 @@ struct QPhysics {
     c.on = false; c.row_active = false; c.box = -2; c.dist = 1.f; c.mu = 0.f; c.D = 0.f;
 #pragma unroll
     for (int r4 = 0; r4 < 4; r4++) c.aref[r4] = 0.f;
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int k = 0; k < 9; k++) c.J[a][k] = 0.f;
+    c.off = v3(0, 0, 0); c.fr[0] = v3(0, 0, 0); c.fr[1] = v3(0, 0, 0); c.fr[2] = v3(0, 0, 0);
   }
 
-  PG_INL void constraint_stage(const TerrainBox* __restrict__ boxes, int nbox, const float* __restrict__ box_fr, int N, int e) {
+  // sh_box: LDS copy of the env's box centres + bounding radii, [b*16 + quad]; sh_key: LDS scratch for the
+  // broad-phase keys of the own foot, [b*64 + lane] (both staged / owned by the calling kernel)
+  PG_INL void constraint_stage(const TerrainBox* __restrict__ boxes, int nbox, const float* __restrict__ box_fr, int N, int e,
+                               const float4* sh_box, const float2* sh_box2, int* sh_cand, const BoxSlots& slots, int quad) {
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       const int j = 3 * l + k;
@@ -411,34 +432,48 @@ struct QPhysics {
       float sr[2], si[5];
       mix(m->floor_solref, m->floor_solimp, m->floor_solmix, m->foot_solref, m->foot_solimp, m->foot_solmix, sr, si);
       float margin = fmaxf(m->floor_margin, m->foot_margin) - fmaxf(m->floor_gap, m->foot_gap);
-      QContact& c = s.con[0];
+      QContact& c = s.con0;
       c.on = true; c.box = -1; c.mu = fmaxf(em.floor_friction, m->foot_friction[0]);
       c.dist = s.footc.z - rad;
       V3 pos = s.footc - v3(0, 0, 1) * (rad + 0.5f * c.dist);
       contact_jac(c, pos, v3(0, 0, 1), v3(0, 1, 0), v3(-1, 0, 0), 1.0f);
       finish_contact(c, sr, si, margin, invw_calf);
     }
-#pragma unroll
-    for (int k = 1; k <= kMaxB; k++) clear_contact(s.con[k]);
     s.nbox = 0;
     if (boxes == nullptr || nbox <= 0) return;
+    {
+      QContact z; clear_contact(z);
+#pragma unroll
+      for (int k = 0; k < kMaxB; k++) slots.store(k, z);
+    }
     const int maxp = m->max_geom_pairs, maxc = m->max_contact_points;
     const bool broad = maxp > -1 && 4 * nbox > maxp;
     const float keyC = rad + m->box_rbound;
-    // pass 1: own foot against every box; penetrating pairs (narrow phase dist < 0) are kept
+    // pass 1a: own foot against every box of the variant, world-AABB test only (LDS-resident centres / extents);
+    //          the few candidates are compacted into a per-lane LDS list
+    const int lane = slots.lane;
+    int ncand = 0;
+#pragma unroll 4
+    for (int b = 0; b < nbox; b++) {
+      const float4 A = sh_box[b * 16 + quad];
+      const float2 H2 = sh_box2[b * 16 + quad];
+      const float pad = rad + 1e-5f;
+      bool cand = fabsf(A.x - s.footc.x) <= A.w + pad && fabsf(A.y - s.footc.y) <= H2.x + pad && fabsf(A.z - s.footc.z) <= H2.y + pad;
+      if (cand && ncand < kMaxCand) { sh_cand[ncand * 64 + lane] = b; ncand++; }
+    }
+    // pass 1b: narrow phase on the compacted candidates (every lane works on its own box); penetrating pairs kept
     QPen pen[kMaxPenQ]; int npen = 0;
 #pragma unroll
     for (int i = 0; i < kMaxPenQ; i++) { pen[i].dist = 1.f; pen[i].key = 3.0e38f; pen[i].idx = 0x7fffffff; pen[i].pos = v3(0, 0, 0); pen[i].n = v3(0, 0, 1); }
-#pragma unroll 4
-    for (int b = 0; b < nbox; b++) {
-      const float4 A = reinterpret_cast<const float4*>(boxes + b)[0];
-      float dc = norm(v3(A.x, A.y, A.z) - s.footc);
-      if (dc <= A.w + rad + 1e-5f) {
+    for (int ci = 0; ci < kMaxCand; ci++) {
+      if (__ballot(ci < ncand) == 0ull) break;
+      if (ci < ncand) {
+        const int b = sh_cand[ci * 64 + lane];
         TerrainBox tb = boxes[b];
         float nd; V3 pw, nw;
         sphere_box(s.footc, rad, tb, nd, pw, nw);
         if (nd < 0.f && npen < kMaxPenQ) {
-          QPen pp; pp.dist = nd; pp.key = dc - keyC; pp.idx = l * nbox + b; pp.pos = pw; pp.n = nw;
+          QPen pp; pp.dist = nd; pp.key = norm(v3(tb.px, tb.py, tb.pz) - s.footc) - keyC; pp.idx = l * nbox + b; pp.pos = pw; pp.n = nw;
 #pragma unroll
           for (int i = 0; i < kMaxPenQ; i++) if (i == npen) pen[i] = pp;
           npen++;
@@ -463,21 +498,21 @@ struct QPhysics {
     if (broad) {
       // pass 2: exact broad-phase rank = number of the 400 (foot, box) pairs that sort before the candidate;
       // every lane counts over its own foot's pairs, the quad sum gives the rank
-#pragma unroll 2
+#pragma unroll 4
       for (int b = 0; b < nbox; b++) {
-        const float4 A = reinterpret_cast<const float4*>(boxes + b)[0];
+        const float4 A = sh_box[b * 16 + quad];
         float key = norm(v3(A.x, A.y, A.z) - s.footc) - keyC;
         int idx = l * nbox + b;
 #pragma unroll
         for (int i = 0; i < kMaxPenQ; i++) {
-          if (i >= ncol) break;
+          if (i >= ncol) continue;
 #pragma unroll
           for (int j = 0; j < 4; j++) crank[j][i] += (key < ckey[j][i] || (key == ckey[j][i] && idx < cidx[j][i])) ? 1 : 0;
         }
       }
 #pragma unroll
       for (int i = 0; i < kMaxPenQ; i++) {
-        if (i >= ncol) break;
+        if (i >= ncol) continue;
 #pragma unroll
         for (int j = 0; j < 4; j++) crank[j][i] = quad_sum_i(crank[j][i]);
       }
@@ -513,7 +548,7 @@ struct QPhysics {
     int nb = 0;
 #pragma unroll
     for (int i = 0; i < kMaxPenQ; i++) {
-      if (i >= ncol) break;
+      if (i >= ncol) continue;
       if (mine[i]) {
         QContact cc;
         cc.on = true; cc.dist = pen[i].dist;
@@ -525,8 +560,7 @@ struct QPhysics {
         make_frame(pen[i].n, n, t1, t2);
         contact_jac(cc, pen[i].pos, n, t1, t2, -1.0f);
         finish_contact(cc, sr, si, margin, invw_calf);
-#pragma unroll
-        for (int k = 0; k < kMaxB; k++) if (k == nb) s.con[1 + k] = cc;
+        slots.store(nb, cc);
         nb++;
       }
     }
@@ -539,23 +573,25 @@ struct QSolver {
   const PgttModel* __restrict__ m;
   QSim& s;
   float qb[6], ql[3], Mab[6], Mal[3], gb[6], gl[3], sb[6], sl[3], fcb[6], fcl[3];
-  float jar_lim[3], jar_con[1 + kMaxB][4];
+  float jar_lim[3], jar0[4];
   float gauss, cost, prev_cost;
   int nslots;     // wave-uniform number of own-box-contact slots in use anywhere in the wave
+  const BoxSlots slots;
 
-  PG_INL QSolver(const PgttModel* m_, QSim& s_) : m(m_), s(s_) {}
+  PG_INL QSolver(const PgttModel* m_, QSim& s_, const BoxSlots& sl_) : m(m_), s(s_), slots(sl_) {}
 
-  PG_INL void con_jx(const QContact& c, const float* xb, const float* xl, float* out4) const {
-    float t[3];
+  // spatial motion of the own calf generated by the generalised vector (xb, xl)
+  PG_INL S6 twist(const float* xb, const float* xl) const {
+    S6 t{v3(0, 0, 0), v3(xb[0], xb[1], xb[2])};
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-      float v = 0.f;
+    for (int k = 0; k < 3; k++) t = t + s.cdr[k] * xb[3 + k];
 #pragma unroll
-      for (int k = 0; k < 6; k++) v += c.J[a][k] * xb[k];
-#pragma unroll
-      for (int k = 0; k < 3; k++) v += c.J[a][6 + k] * xl[k];
-      t[a] = v;
-    }
+    for (int k = 0; k < 3; k++) t = t + s.cdl[k] * xl[k];
+    return t;
+  }
+  PG_INL void con_jx(const QContact& c, S6 tw, float* out4) const {
+    V3 vp = tw.l + cross(tw.a, c.off);
+    float t[3] = {dot(c.fr[0], vp), dot(c.fr[1], vp), dot(c.fr[2], vp)};
     out4[0] = t[0] + c.mu * t[1]; out4[1] = t[0] - c.mu * t[1]; out4[2] = t[0] + c.mu * t[2]; out4[3] = t[0] - c.mu * t[2];
   }
 
@@ -567,21 +603,26 @@ struct QSolver {
     qarrow_mul(s.M, qb, ql, Mab, Mal);
 #pragma unroll
     for (int k = 0; k < 3; k++) jar_lim[k] = s.lim_sign[k] * ql[k] * (s.lim_active[k] ? 1.f : 0.f) - s.lim_aref[k];
-#pragma unroll
-    for (int c = 0; c <= kMaxB; c++) {
-      if (c > nslots) break;
+    const S6 tw = twist(qb, ql);
+    {
       float jx[4];
-      con_jx(s.con[c], qb, ql, jx);
+      con_jx(s.con0, tw, jx);
 #pragma unroll
-      for (int r = 0; r < 4; r++) jar_con[c][r] = (s.con[c].row_active ? jx[r] : 0.f) - s.con[c].aref[r];
+      for (int r = 0; r < 4; r++) jar0[r] = (s.con0.row_active ? jx[r] : 0.f) - s.con0.aref[r];
+    }
+    for (int k = 0; k < nslots; k++) {
+      const QContact cn = slots.load(k);
+      float jx[4];
+      con_jx(cn, tw, jx);
+#pragma unroll
+      for (int r = 0; r < 4; r++) slots.jar(k, r) = (cn.row_active ? jx[r] : 0.f) - cn.aref[r];
     }
     cost = INFINITY; prev_cost = 0.f;
   }
 
   PG_INL void update_constraint() {
     float csum = 0.f, pb[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) pb[i] = 0.f;
+    S6 Fs{v3(0, 0, 0), v3(0, 0, 0)};       // spatial force of the own foot's contacts about the COM
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       float ja = jar_lim[k];
@@ -589,23 +630,27 @@ struct QSolver {
       fcl[k] = s.lim_sign[k] * f;
       csum += ja < 0.f ? s.lim_D[k] * ja * ja : 0.f;
     }
-#pragma unroll
-    for (int c = 0; c <= kMaxB; c++) {
-      if (c > nslots) break;
-      const QContact& cn = s.con[c];
+    auto add_contact = [&](const QContact& cn, const float* ja4) {
       float f[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        float ja = jar_con[c][r];
+        float ja = ja4[r];
         f[r] = ja < 0.f ? -cn.D * ja : 0.f;
         csum += ja < 0.f ? cn.D * ja * ja : 0.f;
       }
       float g[3] = {f[0] + f[1] + f[2] + f[3], cn.mu * (f[0] - f[1]), cn.mu * (f[2] - f[3])};
-#pragma unroll
-      for (int k = 0; k < 6; k++) pb[k] += cn.J[0][k] * g[0] + cn.J[1][k] * g[1] + cn.J[2][k] * g[2];
-#pragma unroll
-      for (int k = 0; k < 3; k++) fcl[k] += cn.J[0][6 + k] * g[0] + cn.J[1][6 + k] * g[1] + cn.J[2][6 + k] * g[2];
+      V3 fw = cn.fr[0] * g[0] + cn.fr[1] * g[1] + cn.fr[2] * g[2];
+      Fs.l = Fs.l + fw; Fs.a = Fs.a + cross(cn.off, fw);
+    };
+    add_contact(s.con0, jar0);
+    for (int k = 0; k < nslots; k++) {
+      const QContact cn = slots.load(k);
+      float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
+      add_contact(cn, ja4);
     }
+    pb[0] = Fs.l.x; pb[1] = Fs.l.y; pb[2] = Fs.l.z;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { pb[3 + k] = dot6(s.cdr[k], Fs); fcl[k] += dot6(s.cdl[k], Fs); }
 #pragma unroll
     for (int i = 0; i < 6; i++) fcb[i] = quad_sum(pb[i]);
     float gbase = 0.f, gleg = 0.f;
@@ -633,34 +678,41 @@ struct QSolver {
     for (int i = 0; i < 6; i++) H.ll[i] = s.M.ll[i];
 #pragma unroll
     for (int k = 0; k < 3; k++) H.ll[tri(k, k)] += jar_lim[k] < 0.f ? s.lim_D[k] : 0.f;
-#pragma unroll
-    for (int c = 0; c <= kMaxB; c++) {
-      if (c > nslots) break;
-      const QContact& cn = s.con[c];
+    auto add_hessian = [&](const QContact& cn, const float* ja4) {
       float w[4];
 #pragma unroll
-      for (int r = 0; r < 4; r++) w[r] = jar_con[c][r] < 0.f ? cn.D : 0.f;
+      for (int r = 0; r < 4; r++) w[r] = ja4[r] < 0.f ? cn.D : 0.f;
       float mu = cn.mu;
       float W00 = w[0] + w[1] + w[2] + w[3], W01 = mu * (w[0] - w[1]), W02 = mu * (w[2] - w[3]);
       float W11 = mu * mu * (w[0] + w[1]), W22 = mu * mu * (w[2] + w[3]);
-      float T[3][9];
+      // world-frame weight A = F^T Wc F (symmetric 3x3), then G = col^T A col over the 9 Jacobian columns
+      V3 r0 = cn.fr[0] * W00 + cn.fr[1] * W01 + cn.fr[2] * W02, r1 = cn.fr[0] * W01 + cn.fr[1] * W11, r2 = cn.fr[0] * W02 + cn.fr[2] * W22;
+      V3 Ax = v3(cn.fr[0].x * r0.x + cn.fr[1].x * r1.x + cn.fr[2].x * r2.x, cn.fr[0].x * r0.y + cn.fr[1].x * r1.y + cn.fr[2].x * r2.y, cn.fr[0].x * r0.z + cn.fr[1].x * r1.z + cn.fr[2].x * r2.z);
+      V3 Ay = v3(Ax.y, cn.fr[0].y * r0.y + cn.fr[1].y * r1.y + cn.fr[2].y * r2.y, cn.fr[0].y * r0.z + cn.fr[1].y * r1.z + cn.fr[2].y * r2.z);
+      V3 Az = v3(Ax.z, Ay.z, cn.fr[0].z * r0.z + cn.fr[1].z * r1.z + cn.fr[2].z * r2.z);
+      V3 col[9], y[9];
+      col[0] = v3(1, 0, 0); col[1] = v3(0, 1, 0); col[2] = v3(0, 0, 1);
 #pragma unroll
-      for (int k = 0; k < 9; k++) {
-        T[0][k] = W00 * cn.J[0][k] + W01 * cn.J[1][k] + W02 * cn.J[2][k];
-        T[1][k] = W01 * cn.J[0][k] + W11 * cn.J[1][k];
-        T[2][k] = W02 * cn.J[0][k] + W22 * cn.J[2][k];
-      }
+      for (int k = 0; k < 3; k++) { col[3 + k] = s.cdr[k].l + cross(s.cdr[k].a, cn.off); col[6 + k] = s.cdl[k].l + cross(s.cdl[k].a, cn.off); }
+#pragma unroll
+      for (int k = 0; k < 9; k++) y[k] = v3(dot(Ax, col[k]), dot(Ay, col[k]), dot(Az, col[k]));
 #pragma unroll
       for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = 0; j <= i; j++) Gbb[tri(i, j)] += cn.J[0][i] * T[0][j] + cn.J[1][i] * T[1][j] + cn.J[2][i] * T[2][j];
+        for (int j = 0; j <= i; j++) Gbb[tri(i, j)] += dot(col[i], y[j]);
 #pragma unroll
       for (int i = 0; i < 3; i++) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) H.lb[i * 6 + k] += cn.J[0][6 + i] * T[0][k] + cn.J[1][6 + i] * T[1][k] + cn.J[2][6 + i] * T[2][k];
+        for (int k = 0; k < 6; k++) H.lb[i * 6 + k] += dot(col[6 + i], y[k]);
 #pragma unroll
-        for (int j = 0; j <= i; j++) H.ll[tri(i, j)] += cn.J[0][6 + i] * T[0][6 + j] + cn.J[1][6 + i] * T[1][6 + j] + cn.J[2][6 + i] * T[2][6 + j];
+        for (int j = 0; j <= i; j++) H.ll[tri(i, j)] += dot(col[6 + i], y[6 + j]);
       }
+    };
+    add_hessian(s.con0, jar0);
+    for (int k = 0; k < nslots; k++) {
+      const QContact cn = slots.load(k);
+      float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
+      add_hessian(cn, ja4);
     }
 #pragma unroll
     for (int i = 0; i < 21; i++) H.bb[i] = s.M.bb[i] + quad_sum(Gbb[i]);
@@ -685,16 +737,22 @@ struct QSolver {
     float gtol = m->tolerance * m->ls_tolerance * smag;
     float mvb[6], mvl[3];
     qarrow_mul(s.M, sb, sl, mvb, mvl);
-    float jv_lim[3], jv_con[1 + kMaxB][4];
+    float jv_lim[3], jv0[4];
 #pragma unroll
     for (int k = 0; k < 3; k++) jv_lim[k] = s.lim_active[k] ? s.lim_sign[k] * sl[k] : 0.f;
-#pragma unroll
-    for (int c = 0; c <= kMaxB; c++) {
-      if (c > nslots) break;
+    const S6 tws = twist(sb, sl);
+    {
       float jx[4];
-      con_jx(s.con[c], sb, sl, jx);
+      con_jx(s.con0, tws, jx);
 #pragma unroll
-      for (int r = 0; r < 4; r++) jv_con[c][r] = s.con[c].row_active ? jx[r] : 0.f;
+      for (int r = 0; r < 4; r++) jv0[r] = s.con0.row_active ? jx[r] : 0.f;
+    }
+    for (int k = 0; k < nslots; k++) {
+      const QContact cn = slots.load(k);
+      float jx[4];
+      con_jx(cn, tws, jx);
+#pragma unroll
+      for (int r = 0; r < 4; r++) slots.jv(k, r) = cn.row_active ? jx[r] : 0.f;
     }
     float ab = 0.f, bb_ = 0.f, eb = 0.f, al = 0.f, bl = 0.f, el = 0.f;
 #pragma unroll
@@ -711,13 +769,19 @@ struct QSolver {
         q0 += d * (0.5f * jar_lim[k] * jar_lim[k]); q1 += d * (jv_lim[k] * jar_lim[k]); q2 += d * (0.5f * jv_lim[k] * jv_lim[k]);
       }
 #pragma unroll
-      for (int c = 0; c <= kMaxB; c++) {
-        if (c > nslots) break;
+      for (int r = 0; r < 4; r++) {
+        float ja = jar0[r], jv = jv0[r];
+        float x = ja + alpha * jv;
+        float d = x < 0.f ? s.con0.D : 0.f;
+        q0 += d * (0.5f * ja * ja); q1 += d * (jv * ja); q2 += d * (0.5f * jv * jv);
+      }
+      for (int k = 0; k < nslots; k++) {
+        const float Dk = slots.at(k, 2);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          float ja = jar_con[c][r], jv = jv_con[c][r];
+          float ja = slots.jar(k, r), jv = slots.jv(k, r);
           float x = ja + alpha * jv;
-          float d = x < 0.f ? s.con[c].D : 0.f;
+          float d = x < 0.f ? Dk : 0.f;
           q0 += d * (0.5f * ja * ja); q1 += d * (jv * ja); q2 += d * (0.5f * jv * jv);
         }
       }
@@ -761,10 +825,10 @@ struct QSolver {
 #pragma unroll
     for (int k = 0; k < 3; k++) { ql[k] += sl[k] * ia; Mal[k] += mvl[k] * ia; jar_lim[k] += jv_lim[k] * ia; }
 #pragma unroll
-    for (int c = 0; c <= kMaxB; c++) {
-      if (c > nslots) break;
+    for (int r = 0; r < 4; r++) jar0[r] += jv0[r] * ia;
+    for (int k = 0; k < nslots; k++) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) jar_con[c][r] += jv_con[c][r] * ia;
+      for (int r = 0; r < 4; r++) slots.jar(k, r) += slots.jv(k, r) * ia;
     }
   }
 
