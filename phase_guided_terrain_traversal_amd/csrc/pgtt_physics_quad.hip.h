@@ -495,8 +495,27 @@ struct QPhysics {
     int ncol = 0;
 #pragma unroll
     for (int i = 0; i < kMaxPenQ; i++) if (__ballot(npen > i) != 0ull) ncol = i + 1;
+    bool need_exact = false;
     if (broad) {
-      // pass 2: exact broad-phase rank = number of the 400 (foot, box) pairs that sort before the candidate;
+      // pass 2a: cheap conservative test.  rank(p) < #pairs with key <= max candidate key; if that count (over the
+      // 400 pairs, quad-summed) is <= max_geom_pairs, every candidate survives MJX's top-k and the exact ranks are
+      // not needed.  d^2 against a slightly inflated threshold: over-counting keeps the test conservative.
+      float kmax = -3.0e38f;
+#pragma unroll
+      for (int i = 0; i < kMaxPenQ; i++) kmax = fmaxf(kmax, pen[i].dist < 0.f ? pen[i].key : -3.0e38f);
+      kmax = fmaxf(fmaxf(quad_bcast<0>(kmax), quad_bcast<1>(kmax)), fmaxf(quad_bcast<2>(kmax), quad_bcast<3>(kmax)));
+      const float thr = (kmax + keyC) * 1.000002f + 1e-7f, thr2 = kmax > -1.0e38f ? thr * thr : -1.f;
+      int cnt = 0;
+#pragma unroll 4
+      for (int b = 0; b < nbox; b++) {
+        const float4 A = sh_box[b * 16 + quad];
+        V3 dv = v3(A.x, A.y, A.z) - s.footc;
+        cnt += dot(dv, dv) <= thr2 ? 1 : 0;
+      }
+      need_exact = quad_sum_i(cnt) > maxp;
+    }
+    if (broad && __ballot(need_exact) != 0ull) {
+      // pass 2b (rare): exact broad-phase rank = number of the 400 (foot, box) pairs that sort before the candidate;
       // every lane counts over its own foot's pairs, the quad sum gives the rank
 #pragma unroll 4
       for (int b = 0; b < nbox; b++) {
@@ -523,7 +542,7 @@ struct QPhysics {
     for (int i = 0; i < kMaxPenQ; i++) {
       mine[i] = false;
 #pragma unroll
-      for (int j = 0; j < 4; j++) taken[j][i] = !(cdist[j][i] < 0.f) || (broad && crank[j][i] >= maxp);
+      for (int j = 0; j < 4; j++) taken[j][i] = !(cdist[j][i] < 0.f) || (broad && need_exact && crank[j][i] >= maxp);
     }
     const int nslot = (maxc > -1 && maxc < 4) ? maxc : 4;
     for (int k = 0; k < nslot; k++) {

@@ -189,3 +189,29 @@ def test_library_refuses_without_bind():
     assert L.pgtt_step(h, None, None) == -2            # PGTT_E_STATE
     assert b"pgtt_bind" in L.pgtt_last_error()
     L.pgtt_destroy(h)
+
+
+def dense_terrain():
+    """Terrain on which MJX's broad-phase top-k (max_geom_pairs = 25) REALLY truncates: 90 tiny 2 x 2 cm tiles
+    (2 mm high, 4 cm pitch) cluster their centres around the spawn area, while ten long slabs (3 cm high) have their
+    centres 0.9 m away.  A foot standing on a slab is then often NOT among the 25 nearest (foot, box) centre pairs,
+    the contact is dropped exactly as in the reference, and the exact rank pass of the HIP kernel is exercised.
+    At most two boxes overlap at any point (kMaxPenQ = 4 per foot is not exceeded)."""
+    T = []
+    for v in range(4):
+        rows = []
+        for i in range(10):
+            for j in range(9):
+                rows.append([(i - 4.5) * 0.04 + 0.01 * v, (j - 4.0) * 0.04, 0.001, 1, 0, 0, 0, 0.01, 0.01, 0.001])
+        for k in range(5):
+            y = (k - 2) * 0.25
+            rows.append([0.9, y, 0.015, 1, 0, 0, 0, 0.85, 0.10, 0.015])
+            rows.append([-0.9, y, 0.015 + 0.002 * v, 0, 0, 0, 1, 0.85, 0.10, 0.015 + 0.002 * v])     # yaw 180 deg
+        T.append(rows)
+    return np.asarray(T, dtype=np.float32)
+
+
+def test_broadphase_truncation_parity():
+    terrain = dense_terrain()
+    st = run_parity("stairs", 128, terrain, steps=25)
+    assert st["box_contacts"] > 500
