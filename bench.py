@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--workload", default="level4", choices=["level4", "flat", "level13_dr"])
+    ap.add_argument("--workload", default="level4", choices=["level4", "flat", "level13_dr", "wfc_dr"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-steps", type=int, default=40)
     args = ap.parse_args()
@@ -66,7 +66,12 @@ def main():
         variant = np.random.Generator(np.random.Philox(key=[2, 0])).integers(0, terrain.shape[0], n * max(world, 1))[off:off + n]
         kw["variant"] = torch.from_numpy(variant.astype(np.int32))
     else:
-        terrain = np.load(os.path.join(assets, "level13.npy")); dr = True
+        if args.workload == "wfc_dr":           # BASELINE configs[3]: WFC-generated terrain (host, once) + full randomize.py DR
+            from phase_guided_terrain_traversal_amd.terrain_gen import create_random_matrix
+            terrain = create_random_matrix(100, 100, 5, 0.05, 0.13, seed=3)
+        else:
+            terrain = np.load(os.path.join(assets, "level13.npy"))
+        dr = True
         out = domain_randomize(mjcf.load_model("stairs"), n, seed=3, terrain=terrain, env_id_offset=off)
         kw = {"variant": torch.from_numpy(out["variant"]), "params": torch.from_numpy(out["params"]),
               "box_friction": torch.from_numpy(out["box_friction"])}
@@ -130,7 +135,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": {"level4": "4096 Go2 envs/GPU, terrains/level4.npy (100 variants x 100 boxes) + 13x9 height scan, no DR (BASELINE configs[2])",
                                     "flat": "4096 Go2 envs/GPU, plane only, no DR (BASELINE configs[1])",
-                                    "level13_dr": "Go2 envs/GPU, level13 + full randomize.py DR (BASELINE configs[3] shape)"}[args.workload],
+                                    "level13_dr": "Go2 envs/GPU, level13 + full randomize.py DR (BASELINE configs[3] shape)",
+                                    "wfc_dr": "Go2 envs/GPU, WFC-generated stairs (terrain_gen.py, 100 variants) + full randomize.py DR (BASELINE configs[3])"}[args.workload],
                        "envs_per_gpu": n, "substeps": 4, "autoreset": True, "actions": "tanh(N(0,0.6)) iid", "parallelism": f"env-shard x{world}"},
             "kernels_ms": {"physics_kernel": phys_ms, "observe_kernel": obs_ms},
             "done_fraction_last_step": done_frac,

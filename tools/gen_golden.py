@@ -316,3 +316,64 @@ for case in range(12):
     cases.append(rec)
 np.savez(os.path.join(OUT, "task_step.npz"), **{f"c{i}_{k}": v for i, r in enumerate(cases) for k, v in r.items()}, ncases=len(cases))
 print("wrote", sorted(os.listdir(OUT)))
+
+# ------------------------------------------------------------------ terrain generator (N3): tile geometry, adjacency rules, WFC samples
+import random as _random
+_cwd = os.getcwd()
+os.chdir(REF)                                   # terrain/generator.py opens ./go2/xmls/scene_mjx_feetonly.xml relatively
+sys.path.insert(0, os.path.join(REF, "terrain"))
+for _name in ("cv2", "noise"):
+    sys.modules[_name] = types.ModuleType(_name)
+_ap = types.ModuleType("alive_progress")
+
+
+class _Bar:
+    def __init__(self, *a, **k): pass
+    def __enter__(self): return lambda *a, **k: None
+    def __exit__(self, *a): return False
+
+
+_ap.alive_bar = _Bar; _ap.alive_it = lambda x, **k: x
+sys.modules["alive_progress"] = _ap
+import terrain.generator as tgen               # noqa: E402
+
+tile_cases = []
+for (w, h, ns) in ((0.4, 0.1, 3), (0.31, 0.05, 2), (0.45, 0.13, 4)):
+    for idx in range(14):
+        tg = tgen.TerrainGenerator(width=w, step_height=h, num_stairs=ns, render=False)
+        tgen.addElement(tg, idx, np.array([0.3, -0.2]))
+        rows = np.array([np.concatenate([b["pos"], b["quat"], b["size"]]) for b in tg.box_data]).reshape(-1, 10)
+        tile_cases.append((w, h, ns, idx, rows))
+
+
+class _Recorder:
+    last = None
+
+    def __init__(self, n_tiles, connections, shape, *a, **k):
+        _Recorder.last = (n_tiles, connections, shape)
+        self.wave = types.SimpleNamespace(wave=np.zeros(shape, dtype=np.int32))
+
+    def init(self, *a, **k): pass
+    def solve(self, *a, **k): pass
+
+
+_real = tgen.WFCCore
+tgen.WFCCore = _Recorder
+tgen.generate_14(5)
+tgen.WFCCore = _real
+n_tiles, conn, _ = _Recorder.last
+dirs = [(-1, 0), (0, -1), (1, 0), (0, 1)]
+conn_arr = np.zeros((14, 4, 14), dtype=np.int8)            # [tile][direction][neighbour tile] allowed?
+for t in range(14):
+    for di, d in enumerate(dirs):
+        for nb in conn[t][d]:
+            conn_arr[t, di, nb] = 1
+waves = []
+for seed in range(12):
+    np.random.seed(seed); _random.seed(seed)
+    waves.append(np.array(tgen.generate_14(5)))
+os.chdir(_cwd)
+np.savez(os.path.join(OUT, "terrain_gen.npz"), connections=conn_arr, directions=np.array(dirs), waves=np.array(waves),
+         **{f"tile{i}_params": np.array(c[:4], dtype=np.float64) for i, c in enumerate(tile_cases)},
+         **{f"tile{i}_boxes": c[4] for i, c in enumerate(tile_cases)}, ntile_cases=len(tile_cases))
+print("terrain_gen fixture: tiles", len(tile_cases), "waves", np.array(waves).shape)
