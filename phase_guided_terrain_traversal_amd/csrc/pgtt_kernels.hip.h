@@ -27,6 +27,9 @@ struct KArgs {
   const unsigned char* mask;
   float yaw_override;          // NaN = use the base yaw
   int write_qpos;              // MODE_FORWARD: store the (quaternion-normalised) qpos
+#ifdef PGTT_TRACE
+  float* trace;                // debugging builds only: per-iteration solver record of env 0
+#endif
 };
 
 // ------------------------------------------------------------------ Philox4x32-10 (independent of the oracle's C)
@@ -66,7 +69,9 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   const PgttModel* __restrict__ m = a.model;
   const PgttConfig* __restrict__ cfg = a.cfg;
   float* __restrict__ S = a.buf.state;
-  const bool lead = valid && l == 0;
+  // Base-body rows are stored by ALL four lanes of the quad (same address, bit-identical value): the kernel has no
+  // region in which only part of a quad is active while replicated state is live ("quad invariants").
+  const bool lead = valid;
 
   QEnvModel em;
   qload_env_model<HAS_DR>(m, a.buf.params, N, e, l, em);
@@ -108,6 +113,9 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   s.niter = 0; s.niter_max = 0;
   QPhysics ph(m, em, s, l);
   QSolver sol(m, s, slots);
+#ifdef PGTT_TRACE
+  if (valid && e == 0 && a.trace) s.tr = a.trace + l;
+#endif
   const int nsub = MODE == MODE_STEP ? cfg->n_substeps : 1;
   const float dt = m->timestep;
   for (int sub = 0; sub < nsub; sub++) {
@@ -169,10 +177,8 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
             for (int k = 0; k < kMaxB; k++) if (k < s.nbox && off + k < 4) {
               dc[2 * (4 + off + k)] = l; dc[2 * (4 + off + k) + 1] = __float_as_int(slots.at(k, 20)); dd[4 + off + k] = slots.at(k, 0); }
           }
-          if (l == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (k >= total) { dc[2 * (4 + k)] = -1; dc[2 * (4 + k) + 1] = -2; dd[4 + k] = 1.0f; }
-          }
+          for (int k = 0; k < 4; k++) if (k >= total) { dc[2 * (4 + k)] = -1; dc[2 * (4 + k) + 1] = -2; dd[4 + k] = 1.0f; }
         }
       }
     }
@@ -208,28 +214,22 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   }
   if (!valid) return;
   if (MODE == MODE_STEP || a.write_qpos) {
-    if (l == 0) {
 #pragma unroll
-      for (int i = 0; i < 7; i++) S[(PGTT_S_QPOS + i) * (long)N + e] = s.qb[i];
-    }
+    for (int i = 0; i < 7; i++) S[(PGTT_S_QPOS + i) * (long)N + e] = s.qb[i];
 #pragma unroll
     for (int k = 0; k < 3; k++) S[(PGTT_S_QPOS + 7 + 3 * l + k) * (long)N + e] = s.ql[k];
   }
   if (MODE == MODE_STEP) {
-    if (l == 0) {
 #pragma unroll
-      for (int i = 0; i < 6; i++) S[(PGTT_S_QVEL + i) * (long)N + e] = s.vb[i];
-    }
+    for (int i = 0; i < 6; i++) S[(PGTT_S_QVEL + i) * (long)N + e] = s.vb[i];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       S[(PGTT_S_QVEL + 6 + 3 * l + k) * (long)N + e] = s.vl[k];
       S[(PGTT_S_MOTOR_TARGETS + 3 * (l ^ 1) + k) * (long)N + e] = s.ctrl[k];
     }
   }
-  if (l == 0) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) S[(PGTT_S_QWARM + i) * (long)N + e] = s.wb[i];
-  }
+  for (int i = 0; i < 6; i++) S[(PGTT_S_QWARM + i) * (long)N + e] = s.wb[i];
 #pragma unroll
   for (int k = 0; k < 3; k++) S[(PGTT_S_QWARM + 6 + 3 * l + k) * (long)N + e] = s.wl[k];
 }

@@ -23,7 +23,15 @@ PG_INL float dpp_f(float x) {
 }
 template <int CTRL>
 PG_INL int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
-PG_INL float quad_sum(float x) { x += dpp_f<0xB1>(x); x += dpp_f<0x4E>(x); return x; }
+// The two butterfly adds must stay plain adds: with contraction on, `p*q + dpp(p*q)` may be fused into
+// fma(p, q, dpp(round(p*q))), which differs between the two lanes of a pair and breaks the invariant that every
+// lane of a quad holds the bit-identical sum (base-body quantities are replicated, never broadcast).
+PG_INL float quad_sum(float x) {
+#pragma clang fp contract(off)
+  x = x + dpp_f<0xB1>(x);
+  x = x + dpp_f<0x4E>(x);
+  return x;
+}
 PG_INL int quad_sum_i(int x) { x += dpp_i<0xB1>(x); x += dpp_i<0x4E>(x); return x; }
 PG_INL V3 quad_sum(V3 a) { return v3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)); }
 template <int J> PG_INL float quad_bcast(float x) { return dpp_f<J * 0x55>(x); }
@@ -99,6 +107,11 @@ struct QSim {
   bool lim_active[3]; float lim_sign[3], lim_D[3], lim_aref[3];
   QContact con0;             // own foot vs the plane (registers)
   int nbox;                  // own box contacts; their records live in LDS (see BoxSlots)
+#ifdef PGTT_TRACE
+  float* tr = nullptr; int trn = 0;
+  PG_INL void rec(float v) { if (tr) tr[4 * trn] = v; trn++; }
+  PG_INL void rec(V3 v) { rec(v.x); rec(v.y); rec(v.z); }
+#endif
   // outputs
   float qacc_b[6], qacc_l[3];
   int niter, niter_max;
@@ -323,6 +336,20 @@ struct QPhysics {
       for (int kk = 0; kk <= k; kk++) s.M.bb[tri(k, kk)] = kk < 3 ? fl[kk] : dot6(s.cdr[kk - 3], f);
     }
     s.LM = s.M;
+#ifdef PGTT_TRACE
+    s.rec(400.f);
+    for (int i = 0; i < 7; i++) s.rec(s.qb[i]);            // 1..7
+    for (int i = 0; i < 3; i++) s.rec(s.ql[i]);            // 8..10
+    s.rec(em.mass0); for (int i = 0; i < 3; i++) s.rec(em.massl[i]);   // 11..14
+    s.rec(xi0); for (int i = 0; i < 6; i++) s.rec(Iw0[i]);             // 15..17, 18..23
+    for (int k = 0; k < 3; k++) s.rec(xil[k]);                          // 24..32
+    s.rec(part); s.rec(pm); s.rec(tot); s.rec(mt); s.rec(s.com);       // 33..35, 36, 37..39, 40, 41..43
+    for (int i = 0; i < 10; i++) s.rec(s.cin0.i[i]);                    // 44..53
+    for (int i = 0; i < 10; i++) s.rec(crb.i[i]);                       // 54..63
+    for (int i = 0; i < 10; i++) s.rec(crb_base.i[i]);                  // 64..73
+    for (int k = 0; k < 3; k++) { s.rec(s.cdr[k].a); s.rec(s.cdr[k].l); }   // 74..91
+    for (int i = 0; i < 21; i++) s.rec(s.M.bb[i]);                      // 92..112
+#endif
     qarrow_factor(s.LM);
   }
 
@@ -370,6 +397,22 @@ struct QPhysics {
       s.qfs_l[k] = -em.damping[k] * s.vl[k] - bias_l[k] + force;
     }
     qarrow_solve(s.LM, s.qfs_b, s.qfs_l, s.qas_b, s.qas_l);
+#ifdef PGTT_TRACE
+    s.rec(500.f);
+    for (int i = 0; i < 21; i++) s.rec(s.LM.bb[i]);       // 1..21
+    for (int i = 0; i < 18; i++) s.rec(s.LM.lb[i]);       // 22..39
+    for (int i = 0; i < 6; i++) s.rec(s.LM.ll[i]);        // 40..45
+    for (int i = 0; i < 6; i++) s.rec(s.M.ll[i]);         // 46..51
+    for (int i = 0; i < 6; i++) s.rec(s.qfs_b[i]);        // 52..57
+    for (int i = 0; i < 3; i++) s.rec(s.qfs_l[i]);        // 58..60
+    for (int i = 0; i < 6; i++) s.rec(s.qas_b[i]);        // 61..66
+    for (int i = 0; i < 3; i++) s.rec(s.qas_l[i]);        // 67..69
+    for (int i = 0; i < 3; i++) s.rec(s.ctrl[i]);         // 70..72
+    for (int i = 0; i < 3; i++) s.rec(bias_l[i]);         // 73..75
+    for (int i = 0; i < 3; i++) s.rec(s.act_force[i]);    // 76..78
+    for (int i = 0; i < 6; i++) s.rec(s.vb[i]);           // 79..84
+    for (int i = 0; i < 3; i++) s.rec(s.vl[i]);           // 85..87
+#endif
   }
 
   PG_INL void contact_jac(QContact& c, V3 pos, V3 n, V3 t1, V3 t2, float sign) const {
@@ -596,6 +639,23 @@ struct QSolver {
   float gauss, cost, prev_cost;
   int nslots;     // wave-uniform number of own-box-contact slots in use anywhere in the wave
   const BoxSlots slots;
+#ifdef PGTT_TRACE
+  float last_alpha = 0.f;
+  PG_INL void rec(float v) { s.rec(v); }
+  PG_INL void rec_state(float tag) {
+    rec(tag); rec(cost); rec(gauss); rec(prev_cost); rec(last_alpha);
+    for (int i = 0; i < 6; i++) rec(qb[i]);
+    for (int i = 0; i < 3; i++) rec(ql[i]);
+    for (int i = 0; i < 6; i++) rec(gb[i]);
+    for (int i = 0; i < 3; i++) rec(gl[i]);
+    for (int i = 0; i < 6; i++) rec(sb[i]);
+    for (int i = 0; i < 3; i++) rec(sl[i]);
+    for (int i = 0; i < 6; i++) rec(fcb[i]);
+    for (int i = 0; i < 3; i++) rec(fcl[i]);
+    for (int i = 0; i < 4; i++) rec(jar0[i]);
+    for (int i = 0; i < 3; i++) rec(jar_lim[i]);
+  }
+#endif
 
   PG_INL QSolver(const PgttModel* m_, QSim& s_, const BoxSlots& sl_) : m(m_), s(s_), slots(sl_) {}
 
@@ -735,6 +795,13 @@ struct QSolver {
     }
 #pragma unroll
     for (int i = 0; i < 21; i++) H.bb[i] = s.M.bb[i] + quad_sum(Gbb[i]);
+#ifdef PGTT_TRACE
+    rec(300.f);
+    for (int i = 0; i < 21; i++) rec(H.bb[i]);
+    for (int i = 0; i < 21; i++) rec(s.M.bb[i]);
+    for (int i = 0; i < 18; i++) rec(H.lb[i]);
+    for (int i = 0; i < 6; i++) rec(H.ll[i]);
+#endif
     qarrow_factor(H);
     float mgb[6], mgl[3];
     qarrow_solve(H, gb, gl, mgb, mgl);
@@ -839,6 +906,9 @@ struct QSolver {
     bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
     float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
     float ia = (improved && !frozen) ? alpha : 0.f;
+#ifdef PGTT_TRACE
+    last_alpha = ia;
+#endif
 #pragma unroll
     for (int i = 0; i < 6; i++) { qb[i] += sb[i] * ia; Mab[i] += mvb[i] * ia; }
 #pragma unroll
@@ -870,6 +940,9 @@ struct QSolver {
       init(kb, kl); update_constraint();
     }
     update_gradient();
+#ifdef PGTT_TRACE
+    rec_state(100.f);
+#endif
     const float scale = m->meaninertia * 18.0f;
     int niter = 0;
     for (;;) {
@@ -885,6 +958,9 @@ struct QSolver {
       update_constraint();
       update_gradient();
       if (!done) niter++;
+#ifdef PGTT_TRACE
+      rec_state(200.f + niter);
+#endif
     }
 #pragma unroll
     for (int i = 0; i < 6; i++) { s.qacc_b[i] = qb[i]; s.wb[i] = qb[i]; }

@@ -9,7 +9,7 @@ from typing import Optional
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpgtt.so")
+LIB_PATH = os.environ.get("PGTT_LIB", os.path.join(_HERE, "libpgtt.so"))   # PGTT_LIB: build experiments only
 _LIB: Optional[C.CDLL] = None
 
 EXPORTS = ["pgtt_create", "pgtt_destroy", "pgtt_set_terrain", "pgtt_bind", "pgtt_reset", "pgtt_step",

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Debug helper: build an alternate libpgtt under alt_build/ with extra compiler flags.
+#   tools/build_variant.sh NAME [extra hipcc flags...]   ->  alt_build/libpgtt_NAME.so   (use with PGTT_LIB=...)
+set +m
+out=$1; shift
+root=$(cd "$(dirname "$0")/.." && pwd)
+cd $root/phase_guided_terrain_traversal_amd/csrc
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $*"
+mkdir -p $root/alt_build/$out
+for v in 0_0_0 0_0_1 0_1_0 0_1_1 1_0_0 1_0_1 1_1_0 1_1_1; do
+  IFS=_ read m d t <<< "$v"
+  hipcc $F -DPG_MODE=$m -DPG_DR=$d -DPG_TERRAIN=$t -c pgtt_physics_inst.hip -o $root/alt_build/$out/p_$v.o 2>$root/alt_build/$out/p_$v.log &
+done
+hipcc $F -c pgtt_api.hip -o $root/alt_build/$out/api.o 2>/dev/null &
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC -o $root/alt_build/libpgtt_$out.so $root/alt_build/$out/*.o && echo built alt_build/libpgtt_$out.so

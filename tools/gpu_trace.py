@@ -1,0 +1,70 @@
+"""Debug builds only (-DPGTT_TRACE): dump the per-iteration Newton record of env 0 after a flat reset."""
+import os, sys, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from tests.test_gpu_parity import make_pair
+from oracle import oracle
+from phase_guided_terrain_traversal_amd import native
+np.set_printoptions(precision=7, suppress=False, linewidth=220)
+name = sys.argv[1]
+n = 64
+env, hb, cs, ms = make_pair("flat_terrain", n, None)
+L0 = native.lib(); L0.pgtt_trace_clear()
+env.reset(3); oracle.reset(cs, ms, None, hb, seed=3, nthreads=8); torch.cuda.synchronize()
+L = native.lib()
+buf = np.zeros(65536, np.float32)
+L.pgtt_trace_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+L.pgtt_trace_read(buf.ctypes.data, buf.size)
+g = {k: v.cpu().numpy() for k, v in env.buffers.items()}
+print(name, "niter gpu", np.bincount(g["dbg_niter"], minlength=6), "cpu", np.bincount(hb["dbg_niter"], minlength=6))
+print("qacc err env0", np.abs(g["state"][37:55, 0] - hb["state"][37:55, 0]).max())
+seg = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+tr = buf.reshape(4, -1, 4)[seg]          # [launch][record][lane]
+print("launch segment", seg)
+os.makedirs("gpurun_out", exist_ok=True)
+np.savez(f"gpurun_out/trace_{name}.npz", tr=tr, gpu_state=g["state"][:, 0], cpu_state=hb["state"][:, 0])
+i = 0
+REC = 1 + 4 + 9 + 9 + 9 + 9 + 4 + 3
+while i < tr.shape[0]:
+    tag = tr[i, 0]
+    if tag == 300.0:
+        blk = tr[i + 1:i + 1 + 66]
+        rep = blk[:42]            # H.bb and M.bb are replicated: all 4 lanes must agree bit-exactly
+        bad = np.nonzero((rep != rep[:, :1]).any(1))[0]
+        print(f"  H record: replicated rows that differ between lanes: {bad.tolist()}")
+        if len(bad): print(rep[bad[:6]])
+        i += 67
+    elif tag == 400.0:
+        blk = tr[i:i + 113]
+        names = {1: "qb", 8: "ql(per-lane)", 11: "mass0", 12: "massl(per-lane)", 15: "xi0", 18: "Iw0", 24: "xil(per-lane)", 33: "part(per-lane)", 36: "pm(per-lane)",
+                 37: "tot", 40: "mt", 41: "com", 44: "cin0", 54: "crb(per-lane)", 64: "crb_base", 74: "cdr", 92: "M.bb"}
+        keys = sorted(names)
+        for a, b in zip(keys, keys[1:] + [113]):
+            seg = blk[a:b]
+            same = bool((seg == seg[:, :1]).all())
+            print(f"  pos[{names[a]}] lanes identical={same}")
+            if not same or "per-lane" in names[a]: print(seg.T)
+        i += 113
+    elif tag == 500.0:
+        blk = tr[i:i + 88]
+        names = {1: "LM.bb", 22: "LM.lb(per-lane)", 40: "LM.ll(per-lane)", 46: "M.ll(per-lane)", 52: "qfs_b", 58: "qfs_l(per-lane)", 61: "qas_b", 67: "qas_l(per-lane)",
+                 70: "ctrl(per-lane)", 73: "bias_l(per-lane)", 76: "act_force(per-lane)", 79: "vb", 85: "vl(per-lane)"}
+        keys = sorted(names)
+        for a, b in zip(keys, keys[1:] + [88]):
+            seg = blk[a:b]
+            same = bool((seg == seg[:, :1]).all())
+            print(f"  vel[{names[a]}] lanes identical={same}")
+            if not same or "per-lane" in names[a]: print(seg.T)
+        i += 88
+    elif tag >= 100.0:
+        blk = tr[i:i + REC]
+        rep_idx = list(range(1, 5)) + list(range(5, 11)) + list(range(14, 20)) + list(range(23, 29)) + list(range(32, 38))
+        rep = blk[rep_idx]
+        bad = [rep_idx[k] for k in np.nonzero((rep != rep[:, :1]).any(1))[0]]
+        print(f"tag {tag:.0f} cost {blk[1,0]:.9g} gauss {blk[2,0]:.9g} prev {blk[3,0]:.9g} alpha {blk[4,0]:.9g} |g| {np.sqrt((blk[14:20,0]**2).sum() + (blk[20:23]**2).sum()):.4g}  lanes-differ rows {bad}")
+        print("   qb", blk[5:11, 0], "ql", blk[11:14].T.reshape(-1))
+        print("   jar0", blk[41:45].T.reshape(-1))
+        i += REC
+    else:
+        break
+print("oracle qacc", hb["state"][37:55, 0])
