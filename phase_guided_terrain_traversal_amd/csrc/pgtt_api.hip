@@ -49,7 +49,7 @@ struct pgtt_env {
   bool ev_valid = false;
 };
 
-#ifdef PGTT_TRACE
+#if defined(PGTT_TRACE) || defined(PGTT_TIME)
 static float* g_trace = nullptr;
 static int g_trace_launch = 0;      // every physics launch records into its own 16384-float segment (mod 4)
 static float* pgtt_trace_buffer() {
@@ -69,7 +69,7 @@ pgtt::KArgs make_args(pgtt_env* h, const unsigned char* mask, float yaw_override
   pgtt::KArgs a;
   a.model = h->d_model; a.cfg = h->d_cfg; a.terrain = h->d_terrain; a.T = h->T; a.B = h->B;
   a.buf = h->buf; a.N = h->N; a.seed = h->seed; a.env_off = h->env_off; a.mask = mask; a.yaw_override = yaw_override; a.write_qpos = 0;
-#ifdef PGTT_TRACE
+#if defined(PGTT_TRACE) || defined(PGTT_TIME)
   a.trace = pgtt_trace_buffer();
 #endif
   return a;
@@ -78,7 +78,7 @@ pgtt::KArgs make_args(pgtt_env* h, const unsigned char* mask, float yaw_override
 template <int MODE>
 void launch_physics(pgtt_env* h, const pgtt::KArgs& a_in, const float* action, hipStream_t st) {
   pgtt::KArgs a = a_in;
-#ifdef PGTT_TRACE
+#if defined(PGTT_TRACE) || defined(PGTT_TIME)
   a.trace = pgtt_trace_buffer() + 16384 * (g_trace_launch++ & 3);
 #endif
   const int nb = (h->N + 15) / 16;                      // one env per quad of lanes: 16 envs per 64-thread block

@@ -27,7 +27,7 @@ struct KArgs {
   const unsigned char* mask;
   float yaw_override;          // NaN = use the base yaw
   int write_qpos;              // MODE_FORWARD: store the (quaternion-normalised) qpos
-#ifdef PGTT_TRACE
+#if defined(PGTT_TRACE) || defined(PGTT_TIME)
   float* trace;                // debugging builds only: per-iteration solver record of env 0
 #endif
 };
@@ -119,9 +119,13 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   const int nsub = MODE == MODE_STEP ? cfg->n_substeps : 1;
   const float dt = m->timestep;
   for (int sub = 0; sub < nsub; sub++) {
+    PG_TICK(s, 9);
     ph.position_stage();
+    PG_TICK(s, 0);
     ph.velocity_stage();
+    PG_TICK(s, 1);
     ph.constraint_stage(boxes, nbox, a.buf.box_friction, N, e, sh_box, sh_box2, sh_cand, slots, quad);
+    PG_TICK(s, 2);
     // ---- sensors of the last forward (pre-integration state), written BEFORE the solve; the accelerometer is
     //      kept as an affine map of qacc[0:6]
     float accA[3][6], acc0[3];
@@ -212,6 +216,11 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
       for (int k = 0; k < 3; k++) s.ql[k] = s.ql[k] + dt * s.vl[k];
     }
   }
+#ifdef PGTT_TIME
+  // stage ticks of the wave that owns env PGTT_TIME (e.g. -DPGTT_TIME=0): 0 position 1 velocity 2 constraint 3 sensors
+  // 4 solver init x3 5 first gradient 6 line search 7 update_constraint 8 update_gradient 9 rest 10 #iterations
+  if (e == PGTT_TIME && a.trace) for (int i = 0; i < 12; i++) a.trace[i] = s.cyc[i];
+#endif
   if (!valid) return;
   if (MODE == MODE_STEP || a.write_qpos) {
 #pragma unroll

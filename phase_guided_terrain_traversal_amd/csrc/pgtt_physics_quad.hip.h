@@ -112,6 +112,16 @@ struct QSim {
   PG_INL void rec(float v) { if (tr) tr[4 * trn] = v; trn++; }
   PG_INL void rec(V3 v) { rec(v.x); rec(v.y); rec(v.z); }
 #endif
+#ifdef PGTT_TIME
+  // stage timer (-DPGTT_TIME builds): cyc[i] accumulates shader-clock ticks of stage i over the launch
+  long long tlast = 0; float cyc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  PG_INL void tick(int stage) { long long t = __builtin_readcyclecounter(); cyc[stage] += (float)(t - tlast); tlast = t; }
+#define PG_TICK(sim, stage) (sim).tick(stage)
+  PG_INL void cyc_iter() { cyc[10] += 1.f; }
+#else
+#define PG_TICK(sim, stage) ((void)0)
+  PG_INL void cyc_iter() {}
+#endif
   // outputs
   float qacc_b[6], qacc_l[3];
   int niter, niter_max;
@@ -638,6 +648,8 @@ struct QSolver {
   float jar_lim[3], jar0[4];
   float gauss, cost, prev_cost;
   int nslots;     // wave-uniform number of own-box-contact slots in use anywhere in the wave
+  bool any_lim, any_con0;   // wave-uniform: some lane has an active joint-limit row / an active plane contact.
+                            // Inactive rows have D = 0 and aref = 0: they add exact zeros, so skipping them is bit-neutral.
   const BoxSlots slots;
 #ifdef PGTT_TRACE
   float last_alpha = 0.f;
@@ -683,7 +695,9 @@ struct QSolver {
 #pragma unroll
     for (int k = 0; k < 3; k++) jar_lim[k] = s.lim_sign[k] * ql[k] * (s.lim_active[k] ? 1.f : 0.f) - s.lim_aref[k];
     const S6 tw = twist(qb, ql);
-    {
+#pragma unroll
+    for (int r = 0; r < 4; r++) jar0[r] = 0.f;
+    if (any_con0) {
       float jx[4];
       con_jx(s.con0, tw, jx);
 #pragma unroll
@@ -703,11 +717,15 @@ struct QSolver {
     float csum = 0.f, pb[6];
     S6 Fs{v3(0, 0, 0), v3(0, 0, 0)};       // spatial force of the own foot's contacts about the COM
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-      float ja = jar_lim[k];
-      float f = ja < 0.f ? -s.lim_D[k] * ja : 0.f;
-      fcl[k] = s.lim_sign[k] * f;
-      csum += ja < 0.f ? s.lim_D[k] * ja * ja : 0.f;
+    for (int k = 0; k < 3; k++) fcl[k] = 0.f;
+    if (any_lim) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        float ja = jar_lim[k];
+        float f = ja < 0.f ? -s.lim_D[k] * ja : 0.f;
+        fcl[k] = s.lim_sign[k] * f;
+        csum += ja < 0.f ? s.lim_D[k] * ja * ja : 0.f;
+      }
     }
     auto add_contact = [&](const QContact& cn, const float* ja4) {
       float f[4];
@@ -721,7 +739,7 @@ struct QSolver {
       V3 fw = cn.fr[0] * g[0] + cn.fr[1] * g[1] + cn.fr[2] * g[2];
       Fs.l = Fs.l + fw; Fs.a = Fs.a + cross(cn.off, fw);
     };
-    add_contact(s.con0, jar0);
+    if (any_con0) add_contact(s.con0, jar0);
     for (int k = 0; k < nslots; k++) {
       const QContact cn = slots.load(k);
       float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
@@ -787,7 +805,7 @@ struct QSolver {
         for (int j = 0; j <= i; j++) H.ll[tri(i, j)] += dot(col[6 + i], y[6 + j]);
       }
     };
-    add_hessian(s.con0, jar0);
+    if (any_con0) add_hessian(s.con0, jar0);
     for (int k = 0; k < nslots; k++) {
       const QContact cn = slots.load(k);
       float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
@@ -813,6 +831,49 @@ struct QSolver {
 
   struct LSPoint { float alpha, cost, d0, d1; };
 
+  // One constraint row at NA trial steps: the quadratic pieces h = D * (ja^2/2, jv ja, jv^2/2) are formed once and added
+  // where the row is active (ja + alpha jv < 0).  m * h with m in {0, 1} keeps the sums those of the un-fused reference.
+  template <int NA>
+  PG_INL static void ls_row(float ja, float jv, float D, const float* al, float (*q)[3]) {
+    const float h0 = D * (0.5f * ja * ja), h1 = D * (jv * ja), h2 = D * (0.5f * jv * jv);
+#pragma unroll
+    for (int a = 0; a < NA; a++) {
+      const float x = ja + al[a] * jv;
+      const float mk = x < 0.f ? 1.0f : 0.f;
+      q[a][0] = fmaf(mk, h0, q[a][0]); q[a][1] = fmaf(mk, h1, q[a][1]); q[a][2] = fmaf(mk, h2, q[a][2]);
+    }
+  }
+
+  // cost and derivatives along the search direction at NA steps; the rows are read ONCE for all NA steps
+  template <int NA>
+  PG_INL void ls_points(const float* al, const float* jv_lim, const float* jv0, float qg0, float qg1, float qg2, LSPoint* out) const {
+    float q[NA][3];
+#pragma unroll
+    for (int a = 0; a < NA; a++) { q[a][0] = 0.f; q[a][1] = 0.f; q[a][2] = 0.f; }
+    if (any_lim) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) ls_row<NA>(jar_lim[k], jv_lim[k], s.lim_D[k], al, q);
+    }
+    if (any_con0) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) ls_row<NA>(jar0[r], jv0[r], s.con0.D, al, q);
+    }
+    for (int k = 0; k < nslots; k++) {
+      const float Dk = slots.at(k, 2);
+#pragma unroll
+      for (int r = 0; r < 4; r++) ls_row<NA>(slots.jar(k, r), slots.jv(k, r), Dk, al, q);
+    }
+#pragma unroll
+    for (int a = 0; a < NA; a++) {
+      const float q0 = quad_sum(q[a][0]) + qg0, q1 = quad_sum(q[a][1]) + qg1, q2 = quad_sum(q[a][2]) + qg2;
+      const float alpha = al[a];
+      out[a].alpha = alpha;
+      out[a].cost = alpha * alpha * q2 + alpha * q1 + q0;
+      out[a].d0 = 2.0f * alpha * q2 + q1;
+      out[a].d1 = 2.0f * q2 + (q2 == 0.f ? kMinVal : 0.f);
+    }
+  }
+
   PG_INL void linesearch(bool frozen) {
     float snb = 0.f, snl = 0.f;
 #pragma unroll
@@ -827,7 +888,9 @@ struct QSolver {
 #pragma unroll
     for (int k = 0; k < 3; k++) jv_lim[k] = s.lim_active[k] ? s.lim_sign[k] * sl[k] : 0.f;
     const S6 tws = twist(sb, sl);
-    {
+#pragma unroll
+    for (int r = 0; r < 4; r++) jv0[r] = 0.f;
+    if (any_con0) {
       float jx[4];
       con_jx(s.con0, tws, jx);
 #pragma unroll
@@ -846,54 +909,21 @@ struct QSolver {
 #pragma unroll
     for (int k = 0; k < 3; k++) { al += sl[k] * Mal[k]; bl += sl[k] * s.qfs_l[k]; el += sl[k] * mvl[k]; }
     const float qg0 = gauss, qg1 = (ab + quad_sum(al)) - (bb_ + quad_sum(bl)), qg2 = 0.5f * (eb + quad_sum(el));
-    auto point = [&](float alpha) {
-      float q0 = 0.f, q1 = 0.f, q2 = 0.f;
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        float x = jar_lim[k] + alpha * jv_lim[k];
-        float d = x < 0.f ? s.lim_D[k] : 0.f;
-        q0 += d * (0.5f * jar_lim[k] * jar_lim[k]); q1 += d * (jv_lim[k] * jar_lim[k]); q2 += d * (0.5f * jv_lim[k] * jv_lim[k]);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        float ja = jar0[r], jv = jv0[r];
-        float x = ja + alpha * jv;
-        float d = x < 0.f ? s.con0.D : 0.f;
-        q0 += d * (0.5f * ja * ja); q1 += d * (jv * ja); q2 += d * (0.5f * jv * jv);
-      }
-      for (int k = 0; k < nslots; k++) {
-        const float Dk = slots.at(k, 2);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          float ja = slots.jar(k, r), jv = slots.jv(k, r);
-          float x = ja + alpha * jv;
-          float d = x < 0.f ? Dk : 0.f;
-          q0 += d * (0.5f * ja * ja); q1 += d * (jv * ja); q2 += d * (0.5f * jv * jv);
-        }
-      }
-      q0 = quad_sum(q0) + qg0; q1 = quad_sum(q1) + qg1; q2 = quad_sum(q2) + qg2;
-      LSPoint p;
-      p.alpha = alpha;
-      p.cost = alpha * alpha * q2 + alpha * q1 + q0;
-      p.d0 = 2.0f * alpha * q2 + q1;
-      p.d1 = 2.0f * q2 + (q2 == 0.f ? kMinVal : 0.f);
-      return p;
-    };
     auto in_bracket = [](const LSPoint& x, const LSPoint& y) {
       return ((x.d0 < y.d0) && (y.d0 < 0.f)) || ((x.d0 > y.d0) && (y.d0 > 0.f));
     };
-    LSPoint p0 = point(0.f);
-    LSPoint lo0 = point(p0.alpha - p0.d0 / p0.d1);
+    LSPoint p0, lo0;
+    { const float a0 = 0.f; ls_points<1>(&a0, jv_lim, jv0, qg0, qg1, qg2, &p0); }
+    { const float a1 = p0.alpha - p0.d0 / p0.d1; ls_points<1>(&a1, jv_lim, jv0, qg0, qg1, qg2, &lo0); }
     bool lesser = lo0.d0 < p0.d0;
     LSPoint hi = lesser ? p0 : lo0, lo = lesser ? lo0 : p0;
     bool swap = true; int it = 0;
     for (;;) {
       bool done = it >= m->ls_iterations || !swap || ((lo.d0 < 0.f) && (lo.d0 > -gtol)) || ((hi.d0 > 0.f) && (hi.d0 < gtol));
       if (__ballot(!done) == 0ull) break;
-      float al3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha)};
+      const float al3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha)};
       LSPoint pt[3];
-#pragma unroll
-      for (int k = 0; k < 3; k++) pt[k] = point(al3[k]);
+      ls_points<3>(al3, jv_lim, jv0, qg0, qg1, qg2, pt);
       LSPoint nlo = lo, nhi = hi;
       bool s1 = in_bracket(nlo, pt[0]); if (s1) nlo = pt[0];
       bool s2 = in_bracket(nlo, pt[2]); if (s2) nlo = pt[2];
@@ -926,6 +956,9 @@ struct QSolver {
 #pragma unroll
     for (int k = 0; k < kMaxB; k++) if (__ballot(s.nbox > k) != 0ull) nb = k + 1;
     nslots = nb;
+    any_lim = __ballot(s.lim_active[0] || s.lim_active[1] || s.lim_active[2]) != 0ull;
+    any_con0 = __ballot(s.con0.row_active) != 0ull;
+    PG_TICK(s, 3);
     init(s.wb, s.wl); update_constraint();
     float cw = cost;
     init(s.qas_b, s.qas_l); update_constraint();
@@ -939,7 +972,9 @@ struct QSolver {
       for (int k = 0; k < 3; k++) kl[k] = usew ? s.wl[k] : s.qas_l[k];
       init(kb, kl); update_constraint();
     }
+    PG_TICK(s, 4);
     update_gradient();
+    PG_TICK(s, 5);
 #ifdef PGTT_TRACE
     rec_state(100.f);
 #endif
@@ -954,9 +989,14 @@ struct QSolver {
       float gn = gnb + quad_sum(gnl);
       bool done = niter >= m->iterations || ((prev_cost - cost) / scale < m->tolerance) || (sqrtf(gn) / scale < m->tolerance);
       if (__ballot(!done) == 0ull) break;
+      PG_TICK(s, 9);
       linesearch(done);
+      PG_TICK(s, 6);
       update_constraint();
+      PG_TICK(s, 7);
       update_gradient();
+      PG_TICK(s, 8);
+      s.cyc_iter();
       if (!done) niter++;
 #ifdef PGTT_TRACE
       rec_state(200.f + niter);

@@ -1,0 +1,29 @@
+"""-DPGTT_TIME=<env> builds only: shader-clock ticks per stage of physics_kernel for the wave that owns that env.
+   usage: PGTT_LIB=alt_build/libpgtt_time.so python tools/gpu_stage_time.py [level4|flat] [num_envs]"""
+import os, sys, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from phase_guided_terrain_traversal_amd import native, configs
+from phase_guided_terrain_traversal_amd.env import Joystick
+wl = sys.argv[1] if len(sys.argv) > 1 else "level4"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+assets = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "phase_guided_terrain_traversal_amd", "assets")
+terrain = None if wl == "flat" else np.load(os.path.join(assets, "terrains", "level4.npy"))
+variant = None if terrain is None else torch.from_numpy(np.random.default_rng(0).integers(0, terrain.shape[0], n).astype(np.int32))
+env = Joystick("flat_terrain" if wl == "flat" else "stairs", configs.training_config(), num_envs=n, terrain=terrain, device="cuda:0", variant=variant, autoreset=True)
+env.reset(seed=1)
+L = native.lib(); L.pgtt_trace_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+g = torch.Generator(device="cuda").manual_seed(0)
+names = ["position", "velocity", "constraint", "sensors", "solver init x2-3", "first gradient", "line search", "update_constraint", "update_gradient", "rest/integrate", "iterations", "-"]
+acc = np.zeros(12)
+for k in range(60):
+    act = torch.tanh(torch.randn(n, 12, device="cuda", generator=g) * 0.6)
+    env.step(act)
+    if k >= 20:
+        buf = np.zeros(65536, np.float32); L.pgtt_trace_read(buf.ctypes.data, buf.size)
+        seg = buf.reshape(4, -1)[:, :12]
+        acc += seg[(k + 2) % 4]           # reset issued launches 0 and 1; step k is launch k + 2, segment = launch % 4
+tot = acc[:10].sum()
+print(f"{wl} n={n}: mean Newton iterations per control step {acc[10] / 40:.2f} (4 substeps)")
+for i in range(10):
+    print(f"  {names[i]:22s} {acc[i] / 40:12.0f} ticks/step  {100 * acc[i] / tot:5.1f} %")
