@@ -95,7 +95,6 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   // by the broad phase), and a per-lane column for the broad-phase keys of the own foot
   __shared__ float4 sh_box[HAS_TERRAIN ? PGTT_MAX_BOX * 16 : 1];      // (cx, cy, cz, hx)
   __shared__ float2 sh_box2[HAS_TERRAIN ? PGTT_MAX_BOX * 16 : 1];     // (hy, hz)
-  __shared__ int sh_cand[HAS_TERRAIN ? kMaxCand * 64 : 1];
   __shared__ float sh_con[HAS_TERRAIN ? kMaxB * kSlotFields * 64 : 1];
   const int quad = threadIdx.x >> 2;
   const BoxSlots slots{sh_con, (int)threadIdx.x};
@@ -120,11 +119,15 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   const float dt = m->timestep;
   for (int sub = 0; sub < nsub; sub++) {
     PG_TICK(s, 9);
-    ph.position_stage();
+    ph.kinematics();
+    PG_TICK(s, 0);
+    if (HAS_TERRAIN) ph.collide(boxes, nbox, sh_box, sh_box2, slots, quad); else s.nbox = 0;
+    PG_TICK(s, 16);
+    ph.inertia();
     PG_TICK(s, 0);
     ph.velocity_stage();
     PG_TICK(s, 1);
-    ph.constraint_stage(boxes, nbox, a.buf.box_friction, N, e, sh_box, sh_box2, sh_cand, slots, quad);
+    ph.constraint_stage(HAS_TERRAIN && boxes != nullptr && nbox > 0, a.buf.box_friction, N, e, slots);
     PG_TICK(s, 2);
     // ---- sensors of the last forward (pre-integration state), written BEFORE the solve; the accelerometer is
     //      kept as an affine map of qacc[0:6]
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
 #ifdef PGTT_TIME
   // stage ticks of the wave that owns env PGTT_TIME (e.g. -DPGTT_TIME=0): 0 position 1 velocity 2 constraint 3 sensors
   // 4 solver init x3 5 first gradient 6 line search 7 update_constraint 8 update_gradient 9 rest 10 #iterations
-  if (e == PGTT_TIME && a.trace) for (int i = 0; i < 12; i++) a.trace[i] = s.cyc[i];
+  if (e == PGTT_TIME && a.trace) for (int i = 0; i < 18; i++) a.trace[i] = s.cyc[i];
 #endif
   if (!valid) return;
   if (MODE == MODE_STEP || a.write_qpos) {

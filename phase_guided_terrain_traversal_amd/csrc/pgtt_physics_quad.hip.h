@@ -39,7 +39,6 @@ template <int J> PG_INL int quad_bcast(int x) { return dpp_i<J * 0x55>(x); }
 
 constexpr int kMaxB = 4;          // box contacts one foot can hold (= max_contact_points of the reference)
 constexpr int kMaxPenQ = 4;       // penetrating (foot, box) pairs tracked per foot
-constexpr int kMaxCand = 16;      // boxes whose world AABB (+ foot radius) contains the foot centre, per foot
 
 struct QArrow { float bb[21]; float lb[18]; float ll[6]; };
 
@@ -114,7 +113,7 @@ struct QSim {
 #endif
 #ifdef PGTT_TIME
   // stage timer (-DPGTT_TIME builds): cyc[i] accumulates shader-clock ticks of stage i over the launch
-  long long tlast = 0; float cyc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = 0; float cyc[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   PG_INL void tick(int stage) { long long t = __builtin_readcyclecounter(); cyc[stage] += (float)(t - tlast); tlast = t; }
 #define PG_TICK(sim, stage) (sim).tick(stage)
   PG_INL void cyc_iter() { cyc[10] += 1.f; }
@@ -279,17 +278,21 @@ struct QPhysics {
     c.i[6] = o.x * mass; c.i[7] = o.y * mass; c.i[8] = o.z * mass; c.i[9] = mass;
   }
 
-  PG_INL void position_stage() {
+  // world inertia of the links, handed from kinematics() to inertia()
+  V3 xi0, xil[3]; float Iw0[6], Iwl[3][6];
+
+  // Stage order of one forward pass (same arithmetic as fwd_position / fwd_velocity / make_constraint, reordered so that
+  // box collision DETECTION runs while only the kinematic frames are live):
+  //   kinematics() -> collide() -> inertia() -> velocity_stage() -> constraint_stage()
+  PG_INL void kinematics() {
     Q4 q0{s.qb[3], s.qb[4], s.qb[5], s.qb[6]};
     normalize4(q0);
     s.qb[3] = q0.w; s.qb[4] = q0.x; s.qb[5] = q0.y; s.qb[6] = q0.z;
     s.p0 = v3(s.qb[0], s.qb[1], s.qb[2]);
     s.R0 = qmat(q0);
-    V3 xi0, xil[3]; float Iw0[6], Iwl[3][6];
     body_inertia(0, s.p0, q0, em.base_ipos, em.mass0, xi0, Iw0);
     s.imu = s.p0 + qrot(v3(m->imu_pos[0], m->imu_pos[1], m->imu_pos[2]), q0);
     V3 pp = s.p0; Q4 pq = q0;
-    V3 part = v3(0, 0, 0); float pm = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       const int j = 3 * l + k, mb = 1 + j;
@@ -305,6 +308,10 @@ struct QPhysics {
     }
     s.footc = pp + qrot(v3(m->foot_geom_pos[l][0], m->foot_geom_pos[l][1], m->foot_geom_pos[l][2]), pq);
     s.sitef = pp + qrot(v3(m->foot_site_pos[l][0], m->foot_site_pos[l][1], m->foot_site_pos[l][2]), pq);
+  }
+
+  PG_INL void inertia() {
+    V3 part = v3(0, 0, 0); float pm = 0.f;
 #pragma unroll
     for (int k = 2; k >= 0; k--) { part = part + xil[k] * em.massl[k]; pm += em.massl[k]; }
     V3 tot = quad_sum(part) + xi0 * em.mass0;
@@ -454,8 +461,9 @@ struct QPhysics {
 
   // sh_box: LDS copy of the env's box centres + bounding radii, [b*16 + quad]; sh_key: LDS scratch for the
   // broad-phase keys of the own foot, [b*64 + lane] (both staged / owned by the calling kernel)
-  PG_INL void constraint_stage(const TerrainBox* __restrict__ boxes, int nbox, const float* __restrict__ box_fr, int N, int e,
-                               const float4* sh_box, const float2* sh_box2, int* sh_cand, const BoxSlots& slots, int quad) {
+  // constraint rows: joint limits, the plane contact, and the box contacts found by collide() (world point / normal parked
+  // in the slot record) completed with their Jacobian frame, impedance and reference acceleration
+  PG_INL void constraint_stage(bool has_boxes, const float* __restrict__ box_fr, int N, int e, const BoxSlots& slots) {
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       const int j = 3 * l + k;
@@ -492,8 +500,36 @@ struct QPhysics {
       contact_jac(c, pos, v3(0, 0, 1), v3(0, 1, 0), v3(-1, 0, 0), 1.0f);
       finish_contact(c, sr, si, margin, invw_calf);
     }
+    if (!has_boxes) return;
+    float sr[2], si[5];
+    mix(m->foot_solref, m->foot_solimp, m->foot_solmix, m->box_solref, m->box_solimp, m->box_solmix, sr, si);
+    float margin = fmaxf(m->foot_margin, m->box_margin) - fmaxf(m->foot_gap, m->box_gap);
+#pragma unroll
+    for (int k = 0; k < kMaxB; k++) {
+      if (__ballot(k < s.nbox) == 0ull) break;
+      if (k < s.nbox) {
+        QContact cc;
+        cc.on = true; cc.dist = slots.at(k, 0);
+        const int b = __float_as_int(slots.at(k, 20));
+        cc.box = b;
+        float bf = box_fr ? box_fr[(long)b * N + e] : m->box_friction[0];
+        cc.mu = fmaxf(bf, m->foot_friction[0]);
+        V3 n, t1, t2;
+        make_frame(v3(slots.at(k, 10), slots.at(k, 11), slots.at(k, 12)), n, t1, t2);
+        contact_jac(cc, v3(slots.at(k, 7), slots.at(k, 8), slots.at(k, 9)), n, t1, t2, -1.0f);
+        finish_contact(cc, sr, si, margin, invw_calf);
+        slots.store(k, cc);
+      }
+    }
+  }
+
+  // box collision detection of the own foot (needs the kinematic frames only): leaves, for each of the s.nbox selected
+  // pairs, (dist, box, world contact point, world normal) in the slot record; constraint_stage() completes them
+  PG_INL void collide(const TerrainBox* __restrict__ boxes, int nbox, const float4* sh_box, const float2* sh_box2, const BoxSlots& slots, int quad) {
+    const float rad = m->foot_radius[l];
     s.nbox = 0;
     if (boxes == nullptr || nbox <= 0) return;
+    PG_TICK(s, 11);
     {
       QContact z; clear_contact(z);
 #pragma unroll
@@ -502,37 +538,64 @@ struct QPhysics {
     const int maxp = m->max_geom_pairs, maxc = m->max_contact_points;
     const bool broad = maxp > -1 && 4 * nbox > maxp;
     const float keyC = rad + m->box_rbound;
-    // pass 1a: own foot against every box of the variant, world-AABB test only (LDS-resident centres / extents);
-    //          the few candidates are compacted into a per-lane LDS list
-    const int lane = slots.lane;
-    int ncand = 0;
-#pragma unroll 4
-    for (int b = 0; b < nbox; b++) {
-      const float4 A = sh_box[b * 16 + quad];
-      const float2 H2 = sh_box2[b * 16 + quad];
+    // pass 1a: own foot against every box of the variant, world-AABB test only (LDS-resident centres / extents).
+    //          Branch-free: the outcome of box b is bit b of a 128-bit per-lane mask, so the LDS reads pipeline.
+    unsigned cm[4] = {0u, 0u, 0u, 0u};
+    {
       const float pad = rad + 1e-5f;
-      bool cand = fabsf(A.x - s.footc.x) <= A.w + pad && fabsf(A.y - s.footc.y) <= H2.x + pad && fabsf(A.z - s.footc.z) <= H2.y + pad;
-      if (cand && ncand < kMaxCand) { sh_cand[ncand * 64 + lane] = b; ncand++; }
+      const float fx = s.footc.x, fy = s.footc.y, fz = s.footc.z;
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        if (w * 32 >= nbox) break;                          // nbox is wave-uniform
+        unsigned bits = 0u;
+        const int left = nbox - w * 32 < 32 ? nbox - w * 32 : 32;   // valid boxes in this word (wave-uniform)
+        // batches of 8 boxes: enough LDS reads in flight, few enough not to be spilled.  The outcome is taken from
+        // the SIGN BIT of max_i(|d_i| - h_i) - pad (no compare -> no SGPR mask per box); `<` instead of `<=` is still
+        // a superset of the penetrating boxes (penetration needs |d_i| < h_i + rad < h_i + pad).  Rows >= nbox of
+        // the LDS tables are allocated but stale: the last batch may read them, their bits are cleared.
+        for (int j0 = 0; j0 < left; j0 += 8) {
+          unsigned byte = 0u;
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const int b = w * 32 + j0 + j < PGTT_MAX_BOX ? w * 32 + j0 + j : PGTT_MAX_BOX - 1;
+            const float4 A = sh_box[b * 16 + quad];
+            const float2 H2 = sh_box2[b * 16 + quad];
+            const float ex = fabsf(A.x - fx) - A.w, ey = fabsf(A.y - fy) - H2.x, ez = fabsf(A.z - fz) - H2.y;
+            const float t = fmaxf(fmaxf(ex, ey), ez) - pad;
+            byte |= (__float_as_uint(t) >> 31) << j;
+          }
+          bits |= byte << j0;
+        }
+        if (left < 32) bits &= (1u << left) - 1u;
+        cm[w] = bits;
+      }
     }
-    // pass 1b: narrow phase on the compacted candidates (every lane works on its own box); penetrating pairs kept
+    PG_TICK(s, 12);
+    // pass 1b: narrow phase on the candidates in box order (every lane pops its own lowest set bit); penetrating pairs kept
     QPen pen[kMaxPenQ]; int npen = 0;
 #pragma unroll
     for (int i = 0; i < kMaxPenQ; i++) { pen[i].dist = 1.f; pen[i].key = 3.0e38f; pen[i].idx = 0x7fffffff; pen[i].pos = v3(0, 0, 0); pen[i].n = v3(0, 0, 1); }
-    for (int ci = 0; ci < kMaxCand; ci++) {
-      if (__ballot(ci < ncand) == 0ull) break;
-      if (ci < ncand) {
-        const int b = sh_cand[ci * 64 + lane];
-        TerrainBox tb = boxes[b];
-        float nd; V3 pw, nw;
-        sphere_box(s.footc, rad, tb, nd, pw, nw);
-        if (nd < 0.f && npen < kMaxPenQ) {
-          QPen pp; pp.dist = nd; pp.key = norm(v3(tb.px, tb.py, tb.pz) - s.footc) - keyC; pp.idx = l * nbox + b; pp.pos = pw; pp.n = nw;
+    for (;;) {
+      const bool have = (cm[0] | cm[1] | cm[2] | cm[3]) != 0u;
+      if (__ballot(have) == 0ull) break;
+      // lowest set bit of the 128-bit mask
+      const int w = cm[0] ? 0 : (cm[1] ? 1 : (cm[2] ? 2 : 3));
+      const unsigned word = w == 0 ? cm[0] : (w == 1 ? cm[1] : (w == 2 ? cm[2] : cm[3]));
+      const int bit = have ? (__ffs(word) - 1) : 0;
+      const unsigned clr = have ? ~(1u << bit) : ~0u;
+      cm[0] &= w == 0 ? clr : ~0u; cm[1] &= w == 1 ? clr : ~0u; cm[2] &= w == 2 ? clr : ~0u; cm[3] &= w == 3 ? clr : ~0u;
+      const int b = have ? w * 32 + bit : 0;
+      TerrainBox tb = boxes[b];
+      float nd; V3 pw, nw;
+      sphere_box(s.footc, rad, tb, nd, pw, nw);
+      if (have && nd < 0.f && npen < kMaxPenQ) {
+        QPen pp; pp.dist = nd; pp.key = norm(v3(tb.px, tb.py, tb.pz) - s.footc) - keyC; pp.idx = l * nbox + b; pp.pos = pw; pp.n = nw;
 #pragma unroll
-          for (int i = 0; i < kMaxPenQ; i++) if (i == npen) pen[i] = pp;
-          npen++;
-        }
+        for (int i = 0; i < kMaxPenQ; i++) if (i == npen) pen[i] = pp;
+        npen++;
       }
     }
+    PG_TICK(s, 13);
     if (__ballot(npen > 0) == 0ull) return;
     // candidate table of the whole quad (replicated): key/idx/dist of lane j's i-th penetrating pair
     float ckey[4][kMaxPenQ], cdist[4][kMaxPenQ]; int cidx[4][kMaxPenQ], crank[4][kMaxPenQ];
@@ -589,6 +652,7 @@ struct QPhysics {
         for (int j = 0; j < 4; j++) crank[j][i] = quad_sum_i(crank[j][i]);
       }
     }
+    PG_TICK(s, 14);
     // replicated selection of the max_contact_points deepest survivors (ties: lower broad-phase rank first)
     bool taken[4][kMaxPenQ], mine[kMaxPenQ];
 #pragma unroll
@@ -613,30 +677,21 @@ struct QPhysics {
 #pragma unroll
         for (int i = 0; i < kMaxPenQ; i++) if (j == bj && i == bi) { taken[j][i] = true; if (j == l) mine[i] = true; }
     }
-    // own selected pairs become own box contacts
-    float sr[2], si[5];
-    mix(m->foot_solref, m->foot_solimp, m->foot_solmix, m->box_solref, m->box_solimp, m->box_solmix, sr, si);
-    float margin = fmaxf(m->foot_margin, m->box_margin) - fmaxf(m->foot_gap, m->box_gap);
+    // own selected pairs: park (dist, box, point, normal) in the slot records
     int nb = 0;
 #pragma unroll
     for (int i = 0; i < kMaxPenQ; i++) {
       if (i >= ncol) continue;
       if (mine[i]) {
-        QContact cc;
-        cc.on = true; cc.dist = pen[i].dist;
-        int b = pen[i].idx - l * nbox;
-        cc.box = b;
-        float bf = box_fr ? box_fr[(long)b * N + e] : m->box_friction[0];
-        cc.mu = fmaxf(bf, m->foot_friction[0]);
-        V3 n, t1, t2;
-        make_frame(pen[i].n, n, t1, t2);
-        contact_jac(cc, pen[i].pos, n, t1, t2, -1.0f);
-        finish_contact(cc, sr, si, margin, invw_calf);
-        slots.store(nb, cc);
+        slots.at(nb, 0) = pen[i].dist;
+        slots.at(nb, 20) = __int_as_float(pen[i].idx - l * nbox);
+        slots.at(nb, 7) = pen[i].pos.x; slots.at(nb, 8) = pen[i].pos.y; slots.at(nb, 9) = pen[i].pos.z;
+        slots.at(nb, 10) = pen[i].n.x; slots.at(nb, 11) = pen[i].n.y; slots.at(nb, 12) = pen[i].n.z;
         nb++;
       }
     }
     s.nbox = nb;
+    PG_TICK(s, 16);
   }
 };
 
