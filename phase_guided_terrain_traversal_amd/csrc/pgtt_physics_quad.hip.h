@@ -1011,6 +1011,9 @@ struct QSolver {
 #pragma unroll
     for (int k = 0; k < kMaxB; k++) if (__ballot(s.nbox > k) != 0ull) nb = k + 1;
     nslots = nb;
+#ifdef PGTT_TIME
+    s.cyc[17] += (float)nb;
+#endif
     any_lim = __ballot(s.lim_active[0] || s.lim_active[1] || s.lim_active[2]) != 0ull;
     any_con0 = __ballot(s.con0.row_active) != 0ull;
     PG_TICK(s, 3);
