@@ -57,12 +57,21 @@ PG_INL int exp_timer(unsigned long long seed, unsigned env, unsigned epoch, unsi
 
 enum { MODE_STEP = 0, MODE_FORWARD = 1 };
 
+// Workgroup i is dispatched to XCD i % 8 and every XCD has its own L2.  Rows of the SoA state are contiguous over envs,
+// so neighbouring envs share 128-byte lines: give each XCD a CONTIGUOUS range of logical blocks (MI355X_MICROARCH.md,
+// "XCD-aware launches").  Identity when the grid is not a multiple of 8.
+PG_INL int xcd_block(int bid, int nblocks) {
+  if (nblocks & 7) return bid;
+  return (bid & 7) * (nblocks >> 3) + (bid >> 3);
+}
+
 // ------------------------------------------------------------------ physics: one env per QUAD of lanes (16 envs per wave)
 template <int MODE, bool HAS_DR, bool HAS_TERRAIN>
 __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __restrict__ action) {
   const int N = a.N;
   const int l = threadIdx.x & 3;                       // leg FL,FR,RL,RR
-  int e = blockIdx.x * 16 + (threadIdx.x >> 2);
+  const int blk = xcd_block(blockIdx.x, gridDim.x);
+  int e = blk * 16 + (threadIdx.x >> 2);
   bool valid = e < N;
   if (!valid) e = N - 1;                               // keep whole quads running (DPP), suppress the stores
   if (MODE != MODE_STEP && a.mask && !a.mask[e]) valid = false;
@@ -328,7 +337,7 @@ PG_INL float gait_get_z(float phi, float swing_height, float swing_min) {
 
 template <int OMODE, bool HAS_TERRAIN>
 __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __restrict__ action) {
-  const int e = blockIdx.x, lane = threadIdx.x, N = a.N;
+  const int e = xcd_block(blockIdx.x, gridDim.x), lane = threadIdx.x, N = a.N;
   if (OMODE != OBS_STEP && a.mask && !a.mask[e]) return;
   const PgttModel* __restrict__ m = a.model;
   const PgttConfig* __restrict__ cfg = a.cfg;
@@ -381,13 +390,31 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
     const TerrainBox* __restrict__ boxes = a.terrain + (long)v * a.B;
     const float rf = sqrtf((0.5f * (PGTT_SCAN_H - 1) * cfg->scan_dist_x) * (0.5f * (PGTT_SCAN_H - 1) * cfg->scan_dist_x) +
                            (0.5f * (PGTT_SCAN_W - 1) * cfg->scan_dist_y) * (0.5f * (PGTT_SCAN_W - 1) * cfg->scan_dist_y)) + 1e-3f;
-    for (int b = 0; b < a.B; b++) {
-      const float4 A = reinterpret_cast<const float4*>(boxes + b)[0];
-      float dx = A.x - bx, dy = A.y - by, rr = A.w + rf;
-      if (dx * dx + dy * dy > rr * rr) continue;            // wave-uniform cull: box cannot reach the footprint
-      TerrainBox tb = boxes[b];
+    // cull, lane-parallel: lane j looks at boxes j and j + 64 (world AABB of the box vs the circle around the scan
+    // footprint); the ballots give the boxes worth a ray test, which are then visited with wave-uniform loads.
+    // min() over the hits does not depend on the visiting order.
+    unsigned long long todo[2];
 #pragma unroll
-      for (int h = 0; h < 2; h++) hit[h] = fminf(hit[h], ray_box_down(tb, org[h]));
+    for (int h = 0; h < 2; h++) {
+      const int b = lane + 64 * h;
+      bool reach = false;
+      if (b < a.B) {
+        const float4 A = reinterpret_cast<const float4*>(boxes + b)[0];
+        const float4 H = reinterpret_cast<const float4*>(boxes + b)[4];
+        reach = fabsf(A.x - bx) <= H.x + rf && fabsf(A.y - by) <= H.y + rf;
+      }
+      todo[h] = __ballot(reach);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      unsigned long long mk = todo[h];
+      while (mk != 0ull) {
+        const int b = 64 * h + __builtin_ctzll(mk);
+        mk &= mk - 1ull;
+        TerrainBox tb = boxes[b];
+#pragma unroll
+        for (int k = 0; k < 2; k++) hit[k] = fminf(hit[k], ray_box_down(tb, org[k]));
+      }
     }
   }
   float z[2];
