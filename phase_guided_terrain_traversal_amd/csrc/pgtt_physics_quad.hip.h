@@ -886,46 +886,66 @@ struct QSolver {
 
   struct LSPoint { float alpha, cost, d0, d1; };
 
-  // One constraint row at NA trial steps: the quadratic pieces h = D * (ja^2/2, jv ja, jv^2/2) are formed once and added
-  // where the row is active (ja + alpha jv < 0).  m * h with m in {0, 1} keeps the sums those of the un-fused reference.
+  // Two constraint rows at NA trial steps, in packed fp32 (v_pk_*: two rows per instruction).  The quadratic pieces
+  // h = D * (ja^2/2, jv ja, jv^2/2) are formed once and added where the row is active (ja + alpha jv < 0); m * h with
+  // m in {0, 1} is exact, so the sums are those of an un-fused evaluation (even and odd rows in separate chains).
+  typedef float f2 __attribute__((ext_vector_type(2)));
   template <int NA>
-  PG_INL static void ls_row(float ja, float jv, float D, const float* al, float (*q)[3]) {
-    const float h0 = D * (0.5f * ja * ja), h1 = D * (jv * ja), h2 = D * (0.5f * jv * jv);
+  PG_INL static void ls_row2(f2 ja, f2 jv, float D, const float* al, f2 (*q)[3]) {
+    const f2 h0 = D * (0.5f * ja * ja), h1 = D * (jv * ja), h2 = D * (0.5f * jv * jv);
 #pragma unroll
     for (int a = 0; a < NA; a++) {
-      const float x = ja + al[a] * jv;
-      const float mk = x < 0.f ? 1.0f : 0.f;
-      q[a][0] = fmaf(mk, h0, q[a][0]); q[a][1] = fmaf(mk, h1, q[a][1]); q[a][2] = fmaf(mk, h2, q[a][2]);
+      const f2 x = ja + al[a] * jv;
+      f2 mk; mk.x = x.x < 0.f ? 1.0f : 0.f; mk.y = x.y < 0.f ? 1.0f : 0.f;
+      q[a][0] = __builtin_elementwise_fma(mk, h0, q[a][0]);
+      q[a][1] = __builtin_elementwise_fma(mk, h1, q[a][1]);
+      q[a][2] = __builtin_elementwise_fma(mk, h2, q[a][2]);
     }
   }
 
   // cost and derivatives along the search direction at NA steps; the rows are read ONCE for all NA steps
   template <int NA>
   PG_INL void ls_points(const float* al, const float* jv_lim, const float* jv0, float qg0, float qg1, float qg2, LSPoint* out) const {
-    float q[NA][3];
+    f2 q[NA][3];
 #pragma unroll
-    for (int a = 0; a < NA; a++) { q[a][0] = 0.f; q[a][1] = 0.f; q[a][2] = 0.f; }
+    for (int a = 0; a < NA; a++) { q[a][0] = f2{0.f, 0.f}; q[a][1] = f2{0.f, 0.f}; q[a][2] = f2{0.f, 0.f}; }
     if (any_lim) {
-#pragma unroll
-      for (int k = 0; k < 3; k++) ls_row<NA>(jar_lim[k], jv_lim[k], s.lim_D[k], al, q);
+      // the three limit rows have their own D each: pairs (row0, row1) and (row2, empty)
+      const f2 ja01{jar_lim[0], jar_lim[1]}, jv01{jv_lim[0], jv_lim[1]}, D01{s.lim_D[0], s.lim_D[1]};
+      const f2 ja2{jar_lim[2], 0.f}, jv2{jv_lim[2], 0.f}, D2{s.lim_D[2], 0.f};
+      ls_row2d<NA>(ja01, jv01, D01, al, q);
+      ls_row2d<NA>(ja2, jv2, D2, al, q);
     }
     if (any_con0) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) ls_row<NA>(jar0[r], jv0[r], s.con0.D, al, q);
+      ls_row2<NA>(f2{jar0[0], jar0[1]}, f2{jv0[0], jv0[1]}, s.con0.D, al, q);
+      ls_row2<NA>(f2{jar0[2], jar0[3]}, f2{jv0[2], jv0[3]}, s.con0.D, al, q);
     }
     for (int k = 0; k < nslots; k++) {
       const float Dk = slots.at(k, 2);
-#pragma unroll
-      for (int r = 0; r < 4; r++) ls_row<NA>(slots.jar(k, r), slots.jv(k, r), Dk, al, q);
+      ls_row2<NA>(f2{slots.jar(k, 0), slots.jar(k, 1)}, f2{slots.jv(k, 0), slots.jv(k, 1)}, Dk, al, q);
+      ls_row2<NA>(f2{slots.jar(k, 2), slots.jar(k, 3)}, f2{slots.jv(k, 2), slots.jv(k, 3)}, Dk, al, q);
     }
 #pragma unroll
     for (int a = 0; a < NA; a++) {
-      const float q0 = quad_sum(q[a][0]) + qg0, q1 = quad_sum(q[a][1]) + qg1, q2 = quad_sum(q[a][2]) + qg2;
+      const float q0 = quad_sum(q[a][0].x + q[a][0].y) + qg0, q1 = quad_sum(q[a][1].x + q[a][1].y) + qg1, q2 = quad_sum(q[a][2].x + q[a][2].y) + qg2;
       const float alpha = al[a];
       out[a].alpha = alpha;
       out[a].cost = alpha * alpha * q2 + alpha * q1 + q0;
       out[a].d0 = 2.0f * alpha * q2 + q1;
       out[a].d1 = 2.0f * q2 + (q2 == 0.f ? kMinVal : 0.f);
+    }
+  }
+  // same with one D per row
+  template <int NA>
+  PG_INL static void ls_row2d(f2 ja, f2 jv, f2 D, const float* al, f2 (*q)[3]) {
+    const f2 h0 = D * (0.5f * ja * ja), h1 = D * (jv * ja), h2 = D * (0.5f * jv * jv);
+#pragma unroll
+    for (int a = 0; a < NA; a++) {
+      const f2 x = ja + al[a] * jv;
+      f2 mk; mk.x = x.x < 0.f ? 1.0f : 0.f; mk.y = x.y < 0.f ? 1.0f : 0.f;
+      q[a][0] = __builtin_elementwise_fma(mk, h0, q[a][0]);
+      q[a][1] = __builtin_elementwise_fma(mk, h1, q[a][1]);
+      q[a][2] = __builtin_elementwise_fma(mk, h2, q[a][2]);
     }
   }
 
