@@ -156,7 +156,9 @@ def run_parity(task, n, terrain, steps, dr=False, autoreset=False, noise=1.0):
     for key, cnt in nviol.items():
         assert cnt <= max(2, 0.005 * well_total), (key, cnt, well_total)
     assert stats["med_gpu"] < 2e-6
-    assert stats["frac_gpu_1e4"] >= stats["frac_fp_1e4"] - 0.03          # no worse than the oracle's own fp32 noise floor
+    # no worse than the oracle's own fp32 noise floor (a distribution statement: needs a sample, 3 sigma of a binomial)
+    slack = 0.03 + 3.0 * np.sqrt(0.06 * 0.94 / (steps * n))
+    assert stats["frac_gpu_1e4"] >= stats["frac_fp_1e4"] - slack
     assert stats["well_frac"] > 0.15
     assert well_flag_mismatch <= max(1, 0.002 * well_total) and well_set_mismatch <= max(1, 0.002 * well_total)   # bit-exact contact indices where well posed
     assert flag_mismatch <= (1 - stats["well_frac"]) * steps * n
@@ -177,6 +179,15 @@ def test_level4_parity():
 def test_level13_dr_autoreset_parity():
     terrain = np.load(os.path.join(ASSETS, "terrains", "level13.npy"))
     run_parity("stairs", 128, terrain, steps=40, dr=True, autoreset=True)
+
+
+def test_ragged_env_counts_parity():
+    """env counts that are not multiples of the 16 envs of a wave (partial last wave, grid not a multiple of the 8
+    XCDs, a single partial wave) go through the same parity bar"""
+    terrain = np.load(os.path.join(ASSETS, "terrains", "level4.npy"))
+    run_parity("stairs", 203, terrain, steps=16)
+    run_parity("flat_terrain", 37, None, steps=16)
+    run_parity("flat_terrain", 5, None, steps=8)
 
 
 def test_library_refuses_without_bind():
