@@ -44,6 +44,11 @@ extern "C" {
 #define PGTT_NSCAN 117
 #define PGTT_OBS 171       /* joystick_pgtt.py:336-349 */
 #define PGTT_PRIV 215      /* joystick_pgtt.py:355-365 */
+#define PGTT_OBS_BASELINE 162   /* go2/joystick.py:336-346: same rows without phase (8) and gait_freq (1) */
+#define PGTT_PRIV_BASELINE 206  /* go2/joystick.py:352-362 */
+/* PgttConfig.method: which of the reference's two task definitions the step computes (training/train.py:112-123, --method) */
+#define PGTT_METHOD_PGTT 0      /* go2/joystick_pgtt.py + configs.default_config() */
+#define PGTT_METHOD_BASELINE 1  /* go2/joystick.py + configs.baseline_config() */
 #define PGTT_NREW 21       /* configs.py:31-59 */
 #define PGTT_NMETRIC 22    /* 21 scaled reward terms + swing_peak (joystick_pgtt.py:122-125) */
 
@@ -135,6 +140,7 @@ typedef struct PgttConfig {
   float scan_dist_x, scan_dist_y; /* 0.1, 0.1 */
   float scan_z_offset;            /* 0.6 (heightmap.py:38) */
   int32_t autoreset;              /* 1: fuse Episode(1000)+AutoReset-to-first-state wrapper semantics into step */
+  int32_t method;                 /* PGTT_METHOD_*: observation layout, H_max definition, clearance target, air-time threshold */
 } PgttConfig;
 
 /* ---------------------------------------------------------------- persistent per-env state rows (float SoA) */
@@ -206,13 +212,13 @@ typedef struct PgttBuffers {
   int32_t* istate;       /* [PGTT_NISTATE][N] */
   float*   frame;        /* [PGTT_NFRAME][N] */
   float*   scan_z;       /* [N][PGTT_NSCAN] hit heights (info["heightscan"][...,2]), row-major 13x9 */
-  float*   obs_state;    /* [N][PGTT_OBS]   row-major, as the trainer consumes it */
-  float*   obs_priv;     /* [N][PGTT_PRIV] */
+  float*   obs_state;    /* [N][state_dim]  row-major, as the trainer consumes it; dims by pgtt_obs_dims(): 171 / 162 */
+  float*   obs_priv;     /* [N][priv_dim]   215 / 206 */
   float*   reward;       /* [N] */
   float*   done;         /* [N] 0/1 */
   float*   metrics;      /* [PGTT_NMETRIC][N] */
   float*   first_state;  /* [PGTT_S_CMD][N] qpos,qvel,qwarm captured at reset (AutoReset) */
-  float*   first_obs;    /* [N][PGTT_OBS + PGTT_PRIV] */
+  float*   first_obs;    /* [N][state_dim + priv_dim] */
   float*   ep_metrics;   /* [PGTT_NMETRIC + 2][N] running episode sums: metrics, sum_reward, length */
   /* optional */
   const float*   params;        /* [PGTT_NPARAM][N] or NULL */
@@ -253,6 +259,8 @@ int pgtt_scan(pgtt_handle h, float yaw_override_or_nan, void* stream);     /* K1
 int pgtt_enable_timing(pgtt_handle h, int enable);
 int pgtt_last_kernel_ms(pgtt_handle h, float* physics_ms, float* observe_ms);
 
+/* observation widths for cfg->method (env.observation_size of the reference, go2/joystick*.py) */
+int pgtt_obs_dims(const PgttConfig* cfg, int* state_dim, int* priv_dim);
 int pgtt_sizeof_model(void);
 int pgtt_sizeof_config(void);
 int pgtt_sizeof_buffers(void);

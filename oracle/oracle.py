@@ -110,11 +110,11 @@ def uniform(seed, env, epoch, stream, idx) -> float:
 class HostBuffers:
     """numpy twins of the PgttBuffers SoA layout, for driving the batch oracle."""
 
-    def __init__(self, n: int, with_params=False, with_variant=False, with_box_friction=False, debug=True):
+    def __init__(self, n: int, with_params=False, with_variant=False, with_box_friction=False, debug=True, method="pgtt"):
         self.n = n
         self.arrays: Dict[str, np.ndarray] = {}
         for spec in abi.BUFFER_SPECS:
-            self.arrays[spec[0]] = np.zeros(abi.buffer_shape(spec, n), dtype=spec[2])
+            self.arrays[spec[0]] = np.zeros(abi.buffer_shape(spec, n, method), dtype=spec[2])
         opt = dict(params=with_params, variant=with_variant, box_friction=with_box_friction, dbg_contact=debug,
                    dbg_dist=debug, dbg_niter=debug)
         for spec in abi.OPTIONAL_SPECS:

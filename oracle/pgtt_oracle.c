@@ -284,6 +284,7 @@ typedef struct PgttOraclePostIn {
   }                                                                                                                      \
   static void reset_all_##SUF(const PgttConfig* cfg, const PgttModel* m, const float* terrain, int T, int Bx, long N,    \
                               const PgttBuffers* B, uint64_t seed, int64_t off, const uint8_t* mask, int nthreads) {     \
+    const int OD = cfg->method == PGTT_METHOD_BASELINE ? PGTT_OBS_BASELINE : PGTT_OBS, PD = OD + (PGTT_PRIV - PGTT_OBS); \
     (void)nthreads;                                                                                                      \
     _Pragma("omp parallel for num_threads(nthreads) schedule(static)")                                                   \
     for (long e = 0; e < N; e++) {                                                                                       \
@@ -298,19 +299,20 @@ typedef struct PgttOraclePostIn {
       for (int f = 0; f < 4; f++) { contact[f] = 0;                                                                      \
         for (int cc = 0; cc < 8; cc++) if (d->contact[cc].foot == lofr[f] && d->contact[cc].box != -2 && d->contact[cc].dist < 0) contact[f] = 1; } \
       write_frame_##SUF(B, N, e, d, contact); write_dbg_##SUF(B, e, d);                                                  \
-      for (int i = 0; i < PGTT_OBS; i++) B->obs_state[e*PGTT_OBS + i] = (float)obs[i];                                   \
-      for (int i = 0; i < PGTT_PRIV; i++) B->obs_priv[e*PGTT_PRIV + i] = (float)priv[i];                                 \
+      for (int i = 0; i < OD; i++) B->obs_state[e*OD + i] = (float)obs[i];                                   \
+      for (int i = 0; i < PD; i++) B->obs_priv[e*PD + i] = (float)priv[i];                                 \
       B->reward[e] = 0; B->done[e] = 0;                                                                                  \
       for (int k = 0; k < PGTT_NMETRIC; k++) B->metrics[(long)k*N + e] = 0;                                              \
       if (B->first_state) for (int i = 0; i < PGTT_S_CMD; i++) B->first_state[(long)i*N + e] = B->state[(long)i*N + e];  \
-      if (B->first_obs) { for (int i = 0; i < PGTT_OBS; i++) B->first_obs[e*(PGTT_OBS + PGTT_PRIV) + i] = (float)obs[i]; \
-        for (int i = 0; i < PGTT_PRIV; i++) B->first_obs[e*(PGTT_OBS + PGTT_PRIV) + PGTT_OBS + i] = (float)priv[i]; }    \
+      if (B->first_obs) { for (int i = 0; i < OD; i++) B->first_obs[e*(OD + PD) + i] = (float)obs[i]; \
+        for (int i = 0; i < PD; i++) B->first_obs[e*(OD + PD) + OD + i] = (float)priv[i]; }    \
       if (B->ep_metrics) for (int k = 0; k < PGTT_NMETRIC + 2; k++) B->ep_metrics[(long)k*N + e] = 0;                    \
       free(d);                                                                                                           \
     }                                                                                                                    \
   }                                                                                                                      \
   static void step_all_##SUF(const PgttConfig* cfg, const PgttModel* m, const float* terrain, int T, int Bx, long N,     \
                              const PgttBuffers* B, const float* action, uint64_t seed, int64_t off, int nthreads) {      \
+    const int OD = cfg->method == PGTT_METHOD_BASELINE ? PGTT_OBS_BASELINE : PGTT_OBS, PD = OD + (PGTT_PRIV - PGTT_OBS); \
     (void)nthreads;                                                                                                      \
     _Pragma("omp parallel for num_threads(nthreads) schedule(static)")                                                   \
     for (long e = 0; e < N; e++) {                                                                                       \
@@ -335,12 +337,12 @@ typedef struct PgttOraclePostIn {
         }                                                                                                                \
       }                                                                                                                  \
       scatter_##SUF(B, N, e, d, &in);                                                                                    \
-      for (int i = 0; i < PGTT_OBS; i++) B->obs_state[e*PGTT_OBS + i] = (float)obs[i];                                   \
-      for (int i = 0; i < PGTT_PRIV; i++) B->obs_priv[e*PGTT_PRIV + i] = (float)priv[i];                                 \
+      for (int i = 0; i < OD; i++) B->obs_state[e*OD + i] = (float)obs[i];                                   \
+      for (int i = 0; i < PD; i++) B->obs_priv[e*PD + i] = (float)priv[i];                                 \
       if (cfg->autoreset && idone) {                                                                                     \
         for (int i = 0; i < PGTT_S_CMD; i++) B->state[(long)i*N + e] = B->first_state[(long)i*N + e];                    \
-        for (int i = 0; i < PGTT_OBS; i++) B->obs_state[e*PGTT_OBS + i] = B->first_obs[e*(PGTT_OBS + PGTT_PRIV) + i];    \
-        for (int i = 0; i < PGTT_PRIV; i++) B->obs_priv[e*PGTT_PRIV + i] = B->first_obs[e*(PGTT_OBS + PGTT_PRIV) + PGTT_OBS + i]; \
+        for (int i = 0; i < OD; i++) B->obs_state[e*OD + i] = B->first_obs[e*(OD + PD) + i];    \
+        for (int i = 0; i < PD; i++) B->obs_priv[e*PD + i] = B->first_obs[e*(OD + PD) + OD + i]; \
       }                                                                                                                  \
       B->reward[e] = (float)reward; B->done[e] = (float)idone;                                                           \
       for (int k = 0; k < PGTT_NMETRIC; k++) B->metrics[(long)k*N + e] = (float)metrics[k];                              \
@@ -372,8 +374,9 @@ BATCH(f64, double)
     for (int i = 0; i < 19; i++) d->qpos[i] = (RT)B->state[PGTT_S_QPOS + i];                                             \
     for (int i = 0; i < 18; i++) { d->qvel[i] = (RT)B->state[PGTT_S_QVEL + i]; d->qacc_warmstart[i] = (RT)B->state[PGTT_S_QWARM + i]; } \
     scatter_##SUF(B, 1, 0, d, &info);                                                                                    \
-    for (int i = 0; i < PGTT_OBS; i++) B->obs_state[i] = (float)obs[i];                                                  \
-    for (int i = 0; i < PGTT_PRIV; i++) B->obs_priv[i] = (float)priv[i];                                                 \
+    const int OD = cfg->method == PGTT_METHOD_BASELINE ? PGTT_OBS_BASELINE : PGTT_OBS, PD = OD + (PGTT_PRIV - PGTT_OBS); \
+    for (int i = 0; i < OD; i++) B->obs_state[i] = (float)obs[i];                                                        \
+    for (int i = 0; i < PD; i++) B->obs_priv[i] = (float)priv[i];                                                        \
     B->reward[0] = (float)reward; B->done[0] = (float)done;                                                              \
     for (int k = 0; k < PGTT_NMETRIC; k++) B->metrics[k] = (float)metrics[k];                                            \
     free(d);                                                                                                             \

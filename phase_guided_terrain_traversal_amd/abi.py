@@ -14,6 +14,14 @@ NQ, NV, NU, NBODY, NLEG = 19, 18, 12, 13, 4
 MAX_BOX, NCON, NEFC = 100, 8, 44
 SCAN_H, SCAN_W, NSCAN = 13, 9, 117
 OBS, PRIV, NREW, NMETRIC = 171, 215, 21, 22
+OBS_BASELINE, PRIV_BASELINE = 162, 206          # go2/joystick.py: no phase (8) / gait_freq (1) rows
+METHODS = {"pgtt": 0, "baseline": 1}
+
+
+def obs_dims(method="pgtt"):
+    """(state, privileged_state) widths of the task definition `method` (name or PGTT_METHOD_* code)."""
+    code = METHODS[method] if isinstance(method, str) else int(method)
+    return (OBS_BASELINE, PRIV_BASELINE) if code == 1 else (OBS, PRIV)
 
 REWARD_KEYS = ["tracking_lin_vel", "tracking_ang_vel", "lin_vel_z", "ang_vel_xy", "orientation",
                "dof_pos_limits", "pose", "termination", "stand_still", "torques", "action_rate",
@@ -65,7 +73,7 @@ class PgttConfig(C.Structure):
         ("reward_scale", f * NREW), ("tracking_sigma", f), ("swing_height", f), ("base_feet_distance", f),
         ("phase_sigma", f), ("cmd_u_max", f * 3), ("cmd_u_min", f * 3), ("cmd_b", f * 3),
         ("gait_freq", f * 2), ("scan_dist_x", f), ("scan_dist_y", f), ("scan_z_offset", f),
-        ("autoreset", i32),
+        ("autoreset", i32), ("method", i32),
     ]
 
 
@@ -92,8 +100,10 @@ OPTIONAL_SPECS = [
 ]
 
 
-def buffer_shape(spec, n: int):
+def buffer_shape(spec, n: int, method="pgtt"):
     name, k, dt, layout = spec
+    od, pd = obs_dims(method)
+    k = {"obs_state": od, "obs_priv": pd, "first_obs": od + pd}.get(name, k)
     return {"soa": (k, n), "aos": (n, k), "vec": (n,)}[layout]
 
 
@@ -139,4 +149,5 @@ def config_struct(cfg: Dict[str, Any]) -> PgttConfig:
     s.gait_freq[0], s.gait_freq[1] = cfg["gait_freq"]
     s.scan_dist_x, s.scan_dist_y, s.scan_z_offset = cfg["scan_dist_x"], cfg["scan_dist_y"], cfg["scan_z_offset"]
     s.autoreset = int(cfg.get("autoreset", 0))
+    s.method = METHODS[cfg.get("method", "pgtt")]
     return s

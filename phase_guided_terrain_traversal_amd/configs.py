@@ -29,12 +29,27 @@ def default_config() -> Dict[str, Any]:
         heighmap_size=(13, 9),
         scan_dist_x=0.1, scan_dist_y=0.1, scan_z_offset=0.6,
         autoreset=0,
+        method="pgtt",
     )
 
 
-def training_config() -> Dict[str, Any]:
-    """default_config() with the overrides of training/train.py:127-129."""
+def baseline_config() -> Dict[str, Any]:
+    """go2/configs.py:82-152 ``baseline_config()``: the comparison task go2/joystick.py is trained with."""
     cfg = default_config()
+    cfg["reward_config"] = dict(
+        scales=dict(tracking_lin_vel=1.0, tracking_ang_vel=0.5, lin_vel_z=-2.0, ang_vel_xy=-0.05,
+                    orientation=-0.2, dof_pos_limits=-1.0, pose=-0.2, termination=-1.0,
+                    stand_still=-0.5, torques=-0.0002, action_rate=-0.005, energy=-0.0005,
+                    feet_clearance=-1.0, feet_height=-0.0, feet_slip=-0.1, feet_air_time=0.1,
+                    feet_phase=0.0, feet_swing=0.0, body_height=-0.0, contact=0.0, center=-0.0),
+        tracking_sigma=0.25, swing_height=-0.2, base_feet_distance=-0.3, phase_sigma=0.05)
+    cfg["method"] = "baseline"
+    return cfg
+
+
+def training_config(method: str = "pgtt") -> Dict[str, Any]:
+    """default_config() / baseline_config() with the overrides of training/train.py:120-129."""
+    cfg = default_config() if method == "pgtt" else baseline_config()
     cfg["command_config"]["u_max"] = [0.6, 0.6, 1.0]
     cfg["command_config"]["u_min"] = [-0.6, -0.6, -1.0]
     cfg["gait_freq"] = [1, 3]

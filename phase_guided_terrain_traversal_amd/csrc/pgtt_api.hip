@@ -111,6 +111,14 @@ extern "C" {
 
 const char* pgtt_last_error(void) { return g_err.c_str(); }
 const char* pgtt_version(void) { return "pgtt-mi355x 0.1 (gfx950)"; }
+int pgtt_obs_dims(const PgttConfig* cfg, int* state_dim, int* priv_dim) {
+  if (!cfg || !state_dim || !priv_dim) return fail(PGTT_E_ARG, "pgtt_obs_dims: null argument");
+  if (cfg->method != PGTT_METHOD_PGTT && cfg->method != PGTT_METHOD_BASELINE) return fail(PGTT_E_ARG, "pgtt_obs_dims: unknown method");
+  *state_dim = cfg->method == PGTT_METHOD_BASELINE ? PGTT_OBS_BASELINE : PGTT_OBS;
+  *priv_dim = cfg->method == PGTT_METHOD_BASELINE ? PGTT_PRIV_BASELINE : PGTT_PRIV;
+  return PGTT_OK;
+}
+
 int pgtt_sizeof_model(void) { return (int)sizeof(PgttModel); }
 int pgtt_sizeof_config(void) { return (int)sizeof(PgttConfig); }
 int pgtt_sizeof_buffers(void) { return (int)sizeof(PgttBuffers); }
@@ -119,6 +127,7 @@ int pgtt_create(const PgttConfig* cfg, const PgttModel* model, int device, int n
   if (!cfg || !model || !out) return fail(PGTT_E_ARG, "pgtt_create: null argument");
   if (num_envs <= 0) return fail(PGTT_E_ARG, "pgtt_create: num_envs must be positive");
   if (cfg->n_substeps < 1 || cfg->n_substeps > 64) return fail(PGTT_E_ARG, "pgtt_create: n_substeps out of range");
+  if (cfg->method != PGTT_METHOD_PGTT && cfg->method != PGTT_METHOD_BASELINE) return fail(PGTT_E_ARG, "pgtt_create: unknown method");
   static const int expect_dof[12] = {9, 10, 11, 6, 7, 8, 15, 16, 17, 12, 13, 14};
   for (int a = 0; a < 12; a++)
     if (model->act_dof[a] != expect_dof[a]) return fail(PGTT_E_ARG, "pgtt_create: actuators must be declared FR,FL,RR,RL on joints FL,FR,RL,RR");

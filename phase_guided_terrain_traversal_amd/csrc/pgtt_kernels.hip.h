@@ -453,6 +453,10 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
   const float zmin = wave_min(fminf(z[0], v1 ? z[1] : INFINITY));
 
   // ---------------- per-env scalars (computed redundantly by every lane from LDS)
+  // method 1 = the baseline task go2/joystick.py: no phase / gait_freq rows in the observation (162 / 206 instead of
+  // 171 / 215), H_max = quadrant max, world-frame clearance target, 0.5 s air-time threshold
+  const bool baseline = cfg->method == PGTT_METHOD_BASELINE;
+  const int OBSD = baseline ? PGTT_OBS_BASELINE : PGTT_OBS, PRIVD = OBSD + (PGTT_PRIV - PGTT_OBS);
   const unsigned id = (unsigned)(a.env_off + e);
   const unsigned ep = (unsigned)I[PGTT_I_RNG_CTR * (long)N + e];
   int step_ctr = I[PGTT_I_STEP * (long)N + e];
@@ -493,13 +497,15 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
       first_contact[f] = (sh_st[PGTT_S_AIR_TIME + f] > 0.f ? 1.f : 0.f) * (filt ? 1.f : 0.f);
       air[f] = sh_st[PGTT_S_AIR_TIME + f] + dt;
       peak[f] = fmaxf(sh_st[PGTT_S_SWING_PEAK + f], sh_fr[PGTT_F_FEET_POS + 3 * f + 2]);
-      hmax[f] = qmax[f] - qmin[f]; hmin[f] = qmin[f];
+      hmax[f] = baseline ? qmax[f] : qmax[f] - qmin[f]; hmin[f] = qmin[f];     // joystick.py:186 vs joystick_pgtt.py:189
     }
   }
 
   // ---------------- observation rows in LDS (joystick_pgtt.py:336-365)
   const float lvl = cfg->noise_level;
-  for (int i = lane; i < PGTT_OBS; i += 64) {
+  for (int io = lane; io < OBSD; io += 64) {
+    // i = row in the PGTT layout; the baseline layout drops rows 30..37 (phase) and 38 + NSCAN (gait_freq)
+    const int i = !baseline ? io : (io < 30 ? io : (io < 30 + PGTT_NSCAN ? io + 8 : io + 9));
     float v;
     if (i < 3) v = sh_fr[PGTT_F_GYRO + i] + (2.f * rng_uniform(a.seed, id, ep, PGTT_RS_GYRO, i) - 1.f) * lvl * cfg->noise_gyro;
     else if (i < 6) v = sh_fr[PGTT_F_GRAVITY + i - 3] + (2.f * rng_uniform(a.seed, id, ep, PGTT_RS_GRAVITY, i - 3) - 1.f) * lvl * cfg->noise_gravity;
@@ -511,7 +517,7 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
     else if (i == 38 + PGTT_NSCAN) v = gait_freq;
     else if (i < 39 + PGTT_NSCAN + 12) v = sh_st[PGTT_S_LAST_ACT + i - (39 + PGTT_NSCAN)];
     else v = sel4(i - (51 + PGTT_NSCAN), cmd[0], cmd[1], cmd[2], 0.f);
-    sh_obs[i] = v;
+    sh_obs[io] = v;
   }
   if (lane < PGTT_PRIV - PGTT_OBS) {
     int i = lane; float v;
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
     else if (i < 37) v = sh_fr[PGTT_F_FEET_VEL + i - 25];
     else if (i < 41) v = sel4(i - 37, air[0], air[1], air[2], air[3]);
     else v = 0.f;
-    sh_obs[PGTT_OBS + PGTT_OBS + i] = v;
+    sh_obs[OBSD + OBSD + i] = v;
   }
   // history buffers (joystick_pgtt.py:319-334): motor_targets in sh_st was written by the physics kernel
   float hist_q = 0.f, hist_v = 0.f; const bool upd = (step_ctr % cfg->history_update_steps) == 0;
@@ -534,7 +540,7 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
     } else { hist_v = sh_st[PGTT_S_QVEL_HIST + lane]; hist_q = sh_st[PGTT_S_QERR_HIST + lane]; }
   }
   __syncthreads();
-  for (int i = lane; i < PGTT_OBS; i += 64) sh_obs[PGTT_OBS + i] = sh_obs[i];     // privileged = state || extras
+  for (int i = lane; i < OBSD; i += 64) sh_obs[OBSD + i] = sh_obs[i];     // privileged = state || extras
   __syncthreads();
 
   // ---------------- rewards, termination, bookkeeping
@@ -582,13 +588,15 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
         float v2 = vx * vx + vy * vy;
         slip += v2 * contact[f];
         float px = sh_fr[PGTT_F_FEET_POS + 3 * f], py = sh_fr[PGTT_F_FEET_POS + 3 * f + 1], pz = sh_fr[PGTT_F_FEET_POS + 3 * f + 2];
-        clear += fabsf(pz - (hmax[f] + cfg->swing_height)) * sqrtf(sqrtf(v2));
+        const float clr = baseline ? sh_fr[PGTT_F_FOOT_SITE_Z + f] - (hmax[f] - cfg->base_feet_distance + cfg->swing_height)   // joystick.py:569-572
+                                   : pz - (hmax[f] + cfg->swing_height);                                                  // joystick_pgtt.py:576-578
+        clear += fabsf(clr) * sqrtf(sqrtf(v2));
         float rz = gait_get_z(phase[f], hmax[f] + cfg->swing_height, cfg->base_feet_distance);
         perr += (pz - rz) * (pz - rz);
         bool swing_mask = phase[f] / (float)(2 * M_PI) >= 0.5f;
         swing += ((pz - cfg->swing_height) * (pz - cfg->swing_height)) * (swing_mask ? 1.f : 0.f);
         con += (swing_mask && contact[f] != 0.f) ? 1.f : 0.f;
-        airr += (air[f] - 0.1f) * first_contact[f];
+        airr += (air[f] - (baseline ? 0.5f : 0.1f)) * first_contact[f];        // joystick.py:591 / joystick_pgtt.py:597
         center += px * px + py * py;
         float er = peak[f] / cfg->swing_height - 1.0f;
         fh += (er * er) * first_contact[f];
@@ -682,16 +690,16 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
   const bool restore = OMODE == OBS_STEP && cfg->autoreset && wdone && a.buf.first_state && a.buf.first_obs;
   if (restore) {
     for (int r = lane; r < PGTT_S_CMD; r += 64) S[r * (long)N + e] = a.buf.first_state[r * (long)N + e];
-    const float* fo = a.buf.first_obs + (long)e * (PGTT_OBS + PGTT_PRIV);
-    for (int i = lane; i < PGTT_OBS; i += 64) a.buf.obs_state[(long)e * PGTT_OBS + i] = fo[i];
-    for (int i = lane; i < PGTT_PRIV; i += 64) a.buf.obs_priv[(long)e * PGTT_PRIV + i] = fo[PGTT_OBS + i];
+    const float* fo = a.buf.first_obs + (long)e * (OBSD + PRIVD);
+    for (int i = lane; i < OBSD; i += 64) a.buf.obs_state[(long)e * OBSD + i] = fo[i];
+    for (int i = lane; i < PRIVD; i += 64) a.buf.obs_priv[(long)e * PRIVD + i] = fo[OBSD + i];
   } else {
-    for (int i = lane; i < PGTT_OBS; i += 64) a.buf.obs_state[(long)e * PGTT_OBS + i] = sh_obs[i];
-    for (int i = lane; i < PGTT_PRIV; i += 64) a.buf.obs_priv[(long)e * PGTT_PRIV + i] = sh_obs[PGTT_OBS + i];
+    for (int i = lane; i < OBSD; i += 64) a.buf.obs_state[(long)e * OBSD + i] = sh_obs[i];
+    for (int i = lane; i < PRIVD; i += 64) a.buf.obs_priv[(long)e * PRIVD + i] = sh_obs[OBSD + i];
   }
   if (OMODE == OBS_RESET) {
     if (a.buf.first_state) for (int r = lane; r < PGTT_S_CMD; r += 64) a.buf.first_state[r * (long)N + e] = sh_st[r];
-    if (a.buf.first_obs) for (int i = lane; i < PGTT_OBS + PGTT_PRIV; i += 64) a.buf.first_obs[(long)e * (PGTT_OBS + PGTT_PRIV) + i] = sh_obs[i];
+    if (a.buf.first_obs) for (int i = lane; i < OBSD + PRIVD; i += 64) a.buf.first_obs[(long)e * (OBSD + PRIVD) + i] = sh_obs[i];
     if (a.buf.ep_metrics) for (int k = lane; k < PGTT_NMETRIC + 2; k += 64) a.buf.ep_metrics[k * (long)N + e] = 0.f;
   }
 }

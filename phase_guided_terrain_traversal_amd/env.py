@@ -29,6 +29,7 @@ class Joystick:
                  model: Optional[Dict[str, Any]] = None):
         self._config = dict(configs.default_config() if config is None else config)
         self._config["autoreset"] = int(autoreset)
+        self.method = self._config.get("method", "pgtt")     # "pgtt" = go2/joystick_pgtt.py, "baseline" = go2/joystick.py
         self.task = task
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
@@ -51,7 +52,7 @@ class Joystick:
         self.buffers: Dict[str, torch.Tensor] = {}
         for spec in abi.BUFFER_SPECS:
             dt = torch.float32 if spec[2] == np.float32 else torch.int32
-            self.buffers[spec[0]] = torch.zeros(abi.buffer_shape(spec, n), dtype=dt, device=self.device)
+            self.buffers[spec[0]] = torch.zeros(abi.buffer_shape(spec, n, self.method), dtype=dt, device=self.device)
         if params is not None:
             self.buffers["params"] = params.to(self.device, torch.float32).contiguous()
             assert self.buffers["params"].shape == (abi.NPARAM, n)
@@ -78,7 +79,8 @@ class Joystick:
 
     @property
     def observation_size(self) -> Dict[str, int]:
-        return {"state": abi.OBS, "privileged_state": abi.PRIV}
+        od, pd = abi.obs_dims(self.method)
+        return {"state": od, "privileged_state": pd}
 
     @property
     def config(self) -> Dict[str, Any]:

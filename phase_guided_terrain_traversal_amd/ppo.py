@@ -111,8 +111,9 @@ def train(env, cfg: PPOConfig, progress_fn: Optional[Callable[[int, Dict[str, fl
     dev = env.device
     n = env.num_envs
     torch.manual_seed(cfg.seed)
-    model = ActorCritic().to(dev)
-    norm_s, norm_p = RunningNorm(abi.OBS, dev), RunningNorm(abi.PRIV, dev)
+    od, pd = env.observation_size["state"], env.observation_size["privileged_state"]
+    model = ActorCritic(od, pd).to(dev)
+    norm_s, norm_p = RunningNorm(od, dev), RunningNorm(pd, dev)
     if restore is not None:
         model.load_state_dict(restore["model"])
         for nm, st in ((norm_s, restore["norm_state"]), (norm_p, restore["norm_priv"])):

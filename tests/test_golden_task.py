@@ -34,9 +34,11 @@ def test_quat_to_yaw(golden_dir):
     assert d.max() < 1e-9
 
 
-def test_scan_grid(golden_dir):
-    """Ray origins of the 13x9 grid (rows front->back, cols left->right, yaw sign) on flat ground."""
-    g = np.load(os.path.join(golden_dir, "scan_grid.npz"))
+@pytest.mark.parametrize("fixture", ["scan_grid.npz", "scan_grid_cpu_twin.npz"])
+def test_scan_grid(golden_dir, fixture):
+    """Ray origins of the 13x9 grid (rows front->back, cols left->right, yaw sign) on flat ground, from both statements
+    of the scan in the reference: go2/heightmap.py (MJX) and deploy/cpu_heightmap/heightmap.py (numpy + mj_ray)."""
+    g = np.load(os.path.join(golden_dir, fixture))
     cs = abi.config_struct(configs.default_config())
     for c, yaw, org in zip(g["centers"], g["yaws"], g["origins"]):
         hit = oracle.scan(cs, None, c, float(yaw), fp64=True)
@@ -52,9 +54,9 @@ class PostIn(C.Structure):
                 ("contact", C.c_int32 * 4)]
 
 
-def _run_case(g, i, ms, cs, fp64):
+def _run_case(g, i, ms, cs, fp64, method="pgtt"):
     k = lambda n: g[f"c{i}_{n}"]
-    hb = oracle.HostBuffers(1)
+    hb = oracle.HostBuffers(1, method=method)
     S, I = hb["state"][:, 0], hb["istate"][:, 0]
     S[abi.S_CMD:abi.S_CMD + 3] = k("in_command")
     S[abi.S_PHASE:abi.S_PHASE + 4] = k("in_phase")
@@ -84,14 +86,19 @@ def _run_case(g, i, ms, cs, fp64):
     return hb
 
 
+@pytest.mark.parametrize("method", ["pgtt", "baseline"])
 @pytest.mark.parametrize("fp64", [True, False])
-def test_task_step_against_reference(golden_dir, ms, fp64):
-    g = np.load(os.path.join(golden_dir, "task_step.npz"))
-    cs = abi.config_struct(configs.training_config())
+def test_task_step_against_reference(golden_dir, ms, fp64, method):
+    """go2/joystick_pgtt.py (method pgtt) and go2/joystick.py (method baseline) executed end to end by the reference's
+    own Python on fake physics outputs (tools/gen_golden.py) vs the oracle's task layer"""
+    g = np.load(os.path.join(golden_dir, "task_step.npz" if method == "pgtt" else "task_step_baseline.npz"))
+    cs = abi.config_struct(configs.training_config(method))
+    od, pd = abi.obs_dims(method)
+    assert g["c0_obs"].shape == (od,) and g["c0_priv"].shape == (pd,)
     # buffers are fp32 even for the f64 build, so compare at fp32 resolution of the magnitudes involved
     tol = 2e-5 if fp64 else 2e-4
     for i in range(int(g["ncases"])):
-        hb = _run_case(g, i, ms, cs, fp64)
+        hb = _run_case(g, i, ms, cs, fp64, method)
         k = lambda n: g[f"c{i}_{n}"]
         S, I = hb["state"][:, 0], hb["istate"][:, 0]
         assert np.abs(hb["obs_state"][0] - k("obs")).max() < tol, i

@@ -17,9 +17,9 @@ from phase_guided_terrain_traversal_amd import abi, configs, mjcf
 ASSETS = os.path.join(os.path.dirname(mjcf.__file__), "assets")
 
 
-def make_pair(task, n, terrain=None, noise=1.0, autoreset=False, dr=False):
+def make_pair(task, n, terrain=None, noise=1.0, autoreset=False, dr=False, method="pgtt"):
     from phase_guided_terrain_traversal_amd.env import Joystick
-    cfg = configs.with_overrides(configs.training_config(), **{"noise_config.level": noise})
+    cfg = configs.with_overrides(configs.training_config(method), **{"noise_config.level": noise})
     model = mjcf.load_model(task)
     kw = {}
     variant = params = bf = None
@@ -39,7 +39,7 @@ def make_pair(task, n, terrain=None, noise=1.0, autoreset=False, dr=False):
     env = Joystick(task, cfg, num_envs=n, terrain=terrain, device="cuda:0", autoreset=autoreset, debug_contacts=True, **kw)
     cfg2 = dict(cfg); cfg2["autoreset"] = int(autoreset)
     cs, ms = abi.config_struct(cfg2), abi.model_struct(model)
-    hb = oracle.HostBuffers(n, with_params=dr, with_variant=variant is not None, with_box_friction=bf is not None)
+    hb = oracle.HostBuffers(n, with_params=dr, with_variant=variant is not None, with_box_friction=bf is not None, method=method)
     if variant is not None:
         hb["variant"][:] = variant
     if dr:
@@ -74,7 +74,7 @@ def per_env_errors(g, hb):
                 metrics=rel(g["metrics"], hb["metrics"], 0))
 
 
-def run_parity(task, n, terrain, steps, dr=False, autoreset=False, noise=1.0):
+def run_parity(task, n, terrain, steps, dr=False, autoreset=False, noise=1.0, method="pgtt"):
     """One control step (4 substeps) from an IDENTICAL state, repeated `steps` times along a GPU rollout.
 
     The reference truncates Newton at 5 iterations (go2_mjx_feetonly.xml:17).  A solve that is CUT at the cap is
@@ -87,8 +87,8 @@ def run_parity(task, n, terrain, steps, dr=False, autoreset=False, noise=1.0):
       * all envs: integers bit-exact; the GPU-vs-oracle error distribution must not be worse than the
         oracle's own fp32-vs-fp64 distribution.
     """
-    env, hb, cs, ms = make_pair(task, n, terrain, noise=noise, dr=dr, autoreset=autoreset)
-    h64 = oracle.HostBuffers(n, with_params=dr, with_variant="variant" in hb.arrays, with_box_friction="box_friction" in hb.arrays)
+    env, hb, cs, ms = make_pair(task, n, terrain, noise=noise, dr=dr, autoreset=autoreset, method=method)
+    h64 = oracle.HostBuffers(n, with_params=dr, with_variant="variant" in hb.arrays, with_box_friction="box_friction" in hb.arrays, method=method)
     for k in ("params", "variant", "box_friction"):
         if k in hb.arrays:
             h64[k][...] = hb[k]
@@ -188,6 +188,17 @@ def test_ragged_env_counts_parity():
     run_parity("stairs", 203, terrain, steps=16)
     run_parity("flat_terrain", 37, None, steps=16)
     run_parity("flat_terrain", 5, None, steps=8)
+
+
+def test_baseline_method_parity():
+    """the comparison task go2/joystick.py (162 / 206 observations, world-frame clearance, H_max = quadrant max)"""
+    terrain = np.load(os.path.join(ASSETS, "terrains", "level4.npy"))
+    st = run_parity("stairs", 128, terrain, steps=30, autoreset=True, method="baseline")
+    env, _, _, _ = make_pair("stairs", 16, terrain, method="baseline")
+    assert env.observation_size == {"state": 162, "privileged_state": 206}
+    obs = env.reset(seed=1)
+    assert obs["state"].shape == (16, 162) and obs["privileged_state"].shape == (16, 206)
+    env.close()
 
 
 def test_library_refuses_without_bind():

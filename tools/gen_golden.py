@@ -222,6 +222,28 @@ for c, y in zip(centers, yaws):
 np.savez(os.path.join(OUT, "scan_grid.npz"), centers=centers, yaws=yaws, origins=np.array(origins), hits=np.array(hits),
          ray_dist=RAY_DIST)
 
+# the reference's second statement of the scan geometry: deploy/cpu_heightmap/heightmap.py (numpy + C mujoco.mj_ray).
+# mj_ray is stubbed to the same constant distance; the same (centre, yaw) cases must give the same 13x9 ray origins.
+import importlib.util as _ilu                                                                   # noqa: E402
+
+
+def _mj_ray(model, data, pnt, vec, geomgroup=None, flg_static=1, bodyexclude=-1, geomid=None):
+    RAY_LOG.append(np.array(pnt, dtype=np.float64))
+    assert np.array_equal(np.asarray(vec), [0, 0, -1.0]) and list(geomgroup) == [1, 0, 0, 0, 1, 1]
+    return RAY_DIST
+
+
+mujoco.mj_ray = _mj_ray
+_spec = _ilu.spec_from_file_location("ref_cpu_heightmap", os.path.join(REF, "deploy", "cpu_heightmap", "heightmap.py"))
+cpu_hm = _ilu.module_from_spec(_spec); _spec.loader.exec_module(cpu_hm)
+origins2, hits2 = [], []
+for c, y in zip(centers, yaws):
+    RAY_LOG.clear()
+    out = cpu_hm.create_sensor_matrix(None, None, c, y)
+    origins2.append(np.array(RAY_LOG).reshape(13, 9, 3)); hits2.append(np.asarray(out))
+np.savez(os.path.join(OUT, "scan_grid_cpu_twin.npz"), centers=centers, yaws=yaws, origins=np.array(origins2), hits=np.array(hits2),
+         ray_dist=RAY_DIST)
+
 # ------------------------------------------------------------------ task step end-to-end with fake physics
 cfg = rconfigs.default_config()
 cfg.command_config.u_max = [0.6, 0.6, 1.0]; cfg.command_config.u_min = [-0.6, -0.6, -1.0]; cfg.gait_freq = [1, 3]   # train.py:127-129
@@ -229,8 +251,8 @@ default_pose = np.array([0, 0.9, -1.8] * 4, dtype=np.float64)
 jnt_range = np.array([[-1.0472, 1.0472], [-1.5708, 3.4907], [-2.7227, -0.83776]] * 4)
 
 
-def make_env():
-    env = object.__new__(jpg.Joystick)
+def make_env(mod, cfg):
+    env = object.__new__(mod.Joystick)
     env._config = cfg
     env._default_pose = default_pose.view(AtArray)
     env._weights = np.array([1.0, 0.1, 0.1] * 4)
@@ -253,68 +275,93 @@ class FakeData:
     pass
 
 
-cases = []
-for case in range(12):
-    env = make_env()
-    d = FakeData()
-    d.qpos = np.concatenate([rng.uniform(-1, 1, 3), rng.normal(size=4), default_pose + rng.uniform(-0.6, 0.6, 12)]).view(AtArray)
-    d.qpos[3:7] /= np.linalg.norm(d.qpos[3:7])
-    if case == 3:   # push joints past the soft limits
-        d.qpos[7:] = np.where(rng.uniform(size=12) < 0.5, jnt_range[:, 0] - 0.01, jnt_range[:, 1] + 0.02)
-    d.qvel = rng.normal(size=18).view(AtArray)
-    d.sensordata = rng.normal(size=49)
-    d.sensordata[25:37] = np.tile([0.2, 0.14, -0.3], 4) + rng.normal(size=12) * 0.05   # feet pos in imu frame
-    if case == 5:
-        d.sensordata[24] = -0.2      # upvector z < 0 -> done
-    Rm = _Rot.from_quat(rng.normal(size=4)).as_matrix()
-    d.site_xmat = np.stack([Rm] + [np.eye(3)] * 4)
-    d.site_xpos = rng.uniform(-1, 1, size=(5, 3))
-    d.actuator_force = rng.uniform(-24, 24, 12)
-    d.xfrc_applied = np.zeros((14, 6))
-    contact = rng.uniform(size=4) < 0.5
-    scan = np.zeros((13, 9, 3)); scan[..., 2] = np.round(rng.uniform(0, 0.3, (13, 9)), 2) * (rng.uniform(size=(13, 9)) < 0.6)
-    FAKE["data"] = d
-    jpg.create_sensor_matrix = lambda mx, dx, center, yaw=0.0, scan=scan: scan.view(AtArray)
-    env.compute_contact = lambda data, a, b, contact=contact: contact
-    env.get_yaw = lambda data: 0.0
-    step0 = int(rng.integers(0, 12)) if case != 1 else 10       # case 1: history-update branch (step % 5 == 0)
-    timer = int(rng.integers(-1, 4)) if case not in (2,) else 1  # case 2: timer expires exactly (1 -> 0)
-    info = {
-        "rng": np.zeros(2, dtype=np.uint32),
-        "command": rng.uniform(-0.6, 0.6, 3) * (0.0 if case == 4 else 1.0),   # case 4: zero command
-        "step": step0, "steps_until_next_cmd": timer,
-        "phase": rng.uniform(0, 2 * np.pi, 4), "phase_dt": 2 * np.pi * 0.02 * 2.0, "gait_freq": 2.0,
-        "last_act": rng.uniform(-1, 1, 12), "last_last_act": rng.uniform(-1, 1, 12),
-        "feet_air_time": rng.uniform(0, 0.3, 4) * (rng.uniform(size=4) < 0.7),
-        "last_contact": rng.uniform(size=4) < 0.5, "swing_peak": -rng.uniform(0, 0.1, 4) * (rng.uniform(size=4) < 0.5),
-        "H_max": 0.1 * np.ones(4), "heightscan": scan, "H_min": np.zeros(4), "motor_targets": np.zeros(12),
-        "qpos_error_history": rng.normal(size=24), "qvel_history": rng.normal(size=24),
-    }
-    metrics = {f"reward/{k}": 0.0 for k in cfg.reward_config.scales.keys()}
-    metrics["swing_peak"] = 0.0
-    info_in = {k: np.array(v, dtype=np.float64) for k, v in info.items() if k not in ("rng", "heightscan")}
-    action = np.tanh(rng.normal(size=12) * 0.6)
-    state = State(FakeData(), None, 0.0, 0.0, metrics, info)
-    out = env.step(state, action.view(AtArray))
-    rec = dict(
-        qpos=np.asarray(d.qpos), qvel=np.asarray(d.qvel), sensordata=d.sensordata, site_imu_mat=Rm,
-        site_foot_z=d.site_xpos[env._feet_site_id][:, 2], actuator_force=d.actuator_force, action=action,
-        scan_z=scan[..., 2].ravel(), contact=contact.astype(np.int32),
-        obs=np.asarray(out.obs["state"], dtype=np.float64), priv=np.asarray(out.obs["privileged_state"], dtype=np.float64),
-        reward=float(out.reward), done=float(out.done),
-        metrics=np.array([float(out.metrics[f"reward/{k}"]) for k in
-                          ["tracking_lin_vel", "tracking_ang_vel", "lin_vel_z", "ang_vel_xy", "orientation", "dof_pos_limits",
-                           "pose", "termination", "stand_still", "torques", "action_rate", "energy", "feet_clearance",
-                           "feet_height", "feet_slip", "feet_air_time", "feet_phase", "feet_swing", "body_height", "contact",
-                           "center"]] + [float(out.metrics["swing_peak"])]),
-    )
-    for k, v in info_in.items():
-        rec["in_" + k] = v
-    for k, v in out.info.items():
-        if k not in ("rng", "heightscan"):
-            rec["out_" + k] = np.array(v, dtype=np.float64)
-    cases.append(rec)
+def gen_cases(mod, cfg, rng):
+    cases = []
+    for case in range(14):        # 12, 13: calm states that track the command -> POSITIVE total reward (un-clipped branch)
+        env = make_env(mod, cfg)
+        d = FakeData()
+        d.qpos = np.concatenate([rng.uniform(-1, 1, 3), rng.normal(size=4), default_pose + rng.uniform(-0.6, 0.6, 12)]).view(AtArray)
+        d.qpos[3:7] /= np.linalg.norm(d.qpos[3:7])
+        if case == 3:   # push joints past the soft limits
+            d.qpos[7:] = np.where(rng.uniform(size=12) < 0.5, jnt_range[:, 0] - 0.01, jnt_range[:, 1] + 0.02)
+        d.qvel = rng.normal(size=18).view(AtArray)
+        d.sensordata = rng.normal(size=49)
+        d.sensordata[25:37] = np.tile([0.2, 0.14, -0.3], 4) + rng.normal(size=12) * 0.05   # feet pos in imu frame
+        if case == 5:
+            d.sensordata[24] = -0.2      # upvector z < 0 -> done
+        Rm = _Rot.from_quat(rng.normal(size=4)).as_matrix()
+        d.site_xmat = np.stack([Rm] + [np.eye(3)] * 4)
+        d.site_xpos = rng.uniform(-1, 1, size=(5, 3))
+        d.actuator_force = rng.uniform(-24, 24, 12)
+        d.xfrc_applied = np.zeros((14, 6))
+        contact = rng.uniform(size=4) < 0.5
+        scan = np.zeros((13, 9, 3)); scan[..., 2] = np.round(rng.uniform(0, 0.3, (13, 9)), 2) * (rng.uniform(size=(13, 9)) < 0.6)
+        FAKE["data"] = d
+        mod.create_sensor_matrix = lambda mx, dx, center, yaw=0.0, scan=scan: scan.view(AtArray)
+        env.compute_contact = lambda data, a, b, contact=contact: contact
+        env.get_yaw = lambda data: 0.0
+        step0 = int(rng.integers(0, 12)) if case != 1 else 10       # case 1: history-update branch (step % 5 == 0)
+        timer = int(rng.integers(-1, 4)) if case not in (2,) else 1  # case 2: timer expires exactly (1 -> 0)
+        info = {
+            "rng": np.zeros(2, dtype=np.uint32),
+            "command": rng.uniform(-0.6, 0.6, 3) * (0.0 if case == 4 else 1.0),   # case 4: zero command
+            "step": step0, "steps_until_next_cmd": timer,
+            "phase": rng.uniform(0, 2 * np.pi, 4), "phase_dt": 2 * np.pi * 0.02 * 2.0, "gait_freq": 2.0,
+            "last_act": rng.uniform(-1, 1, 12), "last_last_act": rng.uniform(-1, 1, 12),
+            "feet_air_time": rng.uniform(0, 0.3, 4) * (rng.uniform(size=4) < 0.7),
+            "last_contact": rng.uniform(size=4) < 0.5, "swing_peak": -rng.uniform(0, 0.1, 4) * (rng.uniform(size=4) < 0.5),
+            "H_max": 0.1 * np.ones(4), "heightscan": scan, "H_min": np.zeros(4), "motor_targets": np.zeros(12),
+            "qpos_error_history": rng.normal(size=24), "qvel_history": rng.normal(size=24),
+        }
+        metrics = {f"reward/{k}": 0.0 for k in cfg.reward_config.scales.keys()}
+        metrics["swing_peak"] = 0.0
+        info_in = {k: np.array(v, dtype=np.float64) for k, v in info.items() if k not in ("rng", "heightscan")}
+        action = np.tanh(rng.normal(size=12) * 0.6)
+        if case >= 12:
+            d.qvel = (np.asarray(d.qvel) * 0.02).view(AtArray)
+            d.qpos[7:] = default_pose + rng.uniform(-0.05, 0.05, 12)
+            d.sensordata = d.sensordata * 0.02
+            d.sensordata[25:37] = np.tile([0.2, 0.14, -0.3], 4) + rng.normal(size=12) * 0.01
+            d.sensordata[22:25] = [0.0, 0.0, 1.0]                                  # upvector
+            d.sensordata[19:21] = info["command"][:2] + rng.normal(size=2) * 0.02     # local linvel tracks the command
+            d.sensordata[2] = info["command"][2] + rng.normal() * 0.02               # gyro z tracks the yaw-rate command
+            d.actuator_force = d.actuator_force * 0.05
+            action = info["last_act"] + rng.normal(size=12) * 0.01
+            contact = (info["phase"] / (2 * np.pi)) < 0.5                            # feet touch exactly in their stance phase
+            env.compute_contact = lambda data, a, b, contact=contact: contact
+            info["last_last_act"] = info["last_act"] + rng.normal(size=12) * 0.01
+            info_in = {k: np.array(v, dtype=np.float64) for k, v in info.items() if k not in ("rng", "heightscan")}
+        state = State(FakeData(), None, 0.0, 0.0, metrics, info)
+        out = env.step(state, action.view(AtArray))
+        rec = dict(
+            qpos=np.asarray(d.qpos), qvel=np.asarray(d.qvel), sensordata=d.sensordata, site_imu_mat=Rm,
+            site_foot_z=d.site_xpos[env._feet_site_id][:, 2], actuator_force=d.actuator_force, action=action,
+            scan_z=scan[..., 2].ravel(), contact=contact.astype(np.int32),
+            obs=np.asarray(out.obs["state"], dtype=np.float64), priv=np.asarray(out.obs["privileged_state"], dtype=np.float64),
+            reward=float(out.reward), done=float(out.done),
+            metrics=np.array([float(out.metrics[f"reward/{k}"]) for k in
+                              ["tracking_lin_vel", "tracking_ang_vel", "lin_vel_z", "ang_vel_xy", "orientation", "dof_pos_limits",
+                               "pose", "termination", "stand_still", "torques", "action_rate", "energy", "feet_clearance",
+                               "feet_height", "feet_slip", "feet_air_time", "feet_phase", "feet_swing", "body_height", "contact",
+                               "center"]] + [float(out.metrics["swing_peak"])]),
+        )
+        for k, v in info_in.items():
+            rec["in_" + k] = v
+        for k, v in out.info.items():
+            if k not in ("rng", "heightscan"):
+                rec["out_" + k] = np.array(v, dtype=np.float64)
+        cases.append(rec)
+    return cases
+
+
+cases = gen_cases(jpg, cfg, rng)
 np.savez(os.path.join(OUT, "task_step.npz"), **{f"c{i}_{k}": v for i, r in enumerate(cases) for k, v in r.items()}, ncases=len(cases))
+# the baseline task (go2/joystick.py + configs.baseline_config(), training/train.py:112-129 --method baseline)
+import go2.joystick as jbase               # noqa: E402
+cfg_b = rconfigs.baseline_config()
+cfg_b.command_config.u_max = [0.6, 0.6, 1.0]; cfg_b.command_config.u_min = [-0.6, -0.6, -1.0]; cfg_b.gait_freq = [1, 3]
+cases_b = gen_cases(jbase, cfg_b, np.random.default_rng(20250705))
+np.savez(os.path.join(OUT, "task_step_baseline.npz"), **{f"c{i}_{k}": v for i, r in enumerate(cases_b) for k, v in r.items()}, ncases=len(cases_b))
 print("wrote", sorted(os.listdir(OUT)))
 
 # ------------------------------------------------------------------ terrain generator (N3): tile geometry, adjacency rules, WFC samples

@@ -29,9 +29,9 @@ def load_terrain(spec):
 
 
 def run_training(args):
-    if args.method != "pgtt":
-        raise SystemExit("only --method pgtt is implemented (the baseline env go2/joystick.py is row N4 of SURVEY 8f)")
-    cfg = configs.training_config()                               # train.py:127-129 overrides
+    if args.method not in ("pgtt", "baseline"):
+        raise SystemExit("--method must be pgtt (go2/joystick_pgtt.py) or baseline (go2/joystick.py)")
+    cfg = configs.training_config(args.method)                    # train.py:120-129: config by method + overrides
     model = mjcf.load_model(args.task_name)
     terrain = load_terrain(args.terrain_file) if args.task_name == "stairs" else None
     dr = domain_randomize(model, args.num_envs, seed=args.index, terrain=terrain)      # once per env index
