@@ -84,7 +84,7 @@ def main():
     def run(k0, k1):
         for k in range(k0, k1):
             obs, reward, done, info = env.step(pool[k % len(pool)])
-            reducer.accumulate(info["metrics"], reward, done)
+            reducer.accumulate_block(env.step_block)
             if (k + 1) % 20 == 0:
                 reducer.reduce()
 

@@ -44,17 +44,25 @@ class MetricReducer:
     def __init__(self, device: torch.device):
         self.device = device
         self.acc = torch.zeros(self.SIZE, dtype=torch.float32, device=device)
+        self.count = 0.0          # env-steps accumulated since the last reduce (kept on the host: no kernel per step)
 
     def accumulate(self, metrics: torch.Tensor, reward: torch.Tensor, done: torch.Tensor) -> None:
         """metrics [22, N], reward [N], done [N] of one step (local shard)."""
         self.acc[:abi.NMETRIC] += metrics.sum(dim=1)
         self.acc[abi.NMETRIC] += reward.sum()
         self.acc[abi.NMETRIC + 1] += done.sum()
-        self.acc[abi.NMETRIC + 2] += float(reward.shape[0])
+        self.count += float(reward.shape[0])
+
+    def accumulate_block(self, block: torch.Tensor) -> None:
+        """`Joystick.step_block` ([22 metrics; reward; done][N]) of one step: one reduction kernel + one add."""
+        self.acc[:abi.NMETRIC + 2] += block.sum(dim=1)
+        self.count += float(block.shape[1])
 
     def reduce(self) -> Dict[str, torch.Tensor]:
         """Sum over ranks (one RCCL all-reduce), reset the local accumulator, return global means."""
         buf = self.acc.clone()
+        buf[abi.NMETRIC + 2] += self.count
+        self.count = 0.0
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         self.acc.zero_()

@@ -53,6 +53,12 @@ class Joystick:
         for spec in abi.BUFFER_SPECS:
             dt = torch.float32 if spec[2] == np.float32 else torch.int32
             self.buffers[spec[0]] = torch.zeros(abi.buffer_shape(spec, n, self.method), dtype=dt, device=self.device)
+        # the 22 metric rows, the reward row and the done row live in ONE [24][N] block, so that a trainer can reduce
+        # them over the envs with a single kernel (distributed.MetricReducer.accumulate_block)
+        self.step_block = torch.zeros((abi.NMETRIC + 2, n), dtype=torch.float32, device=self.device)
+        self.buffers["metrics"] = self.step_block[:abi.NMETRIC]
+        self.buffers["reward"] = self.step_block[abi.NMETRIC]
+        self.buffers["done"] = self.step_block[abi.NMETRIC + 1]
         if params is not None:
             self.buffers["params"] = params.to(self.device, torch.float32).contiguous()
             assert self.buffers["params"].shape == (abi.NPARAM, n)
