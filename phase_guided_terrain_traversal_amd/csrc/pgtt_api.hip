@@ -11,10 +11,12 @@
 
 #include "pgtt_kernels.hip.h"
 
-// the eight physics_kernel instantiations live in their own translation units (pgtt_physics_inst.hip,
-// compiled in parallel); this file only sees their host launchers
-#define PG_DECL(M, D, T) void pgtt_launch_physics_##M##_##D##_##T(int nblocks, hipStream_t st, const pgtt::KArgs& a, const float* action);
-PG_DECL(0, 0, 0) PG_DECL(0, 0, 1) PG_DECL(0, 1, 0) PG_DECL(0, 1, 1) PG_DECL(1, 0, 0) PG_DECL(1, 0, 1) PG_DECL(1, 1, 0) PG_DECL(1, 1, 1)
+// the physics_kernel instantiations (2 lane layouts x step/forward x DR x terrain) live in their own translation units
+// (pgtt_physics_inst.hip, compiled in parallel); this file only sees their host launchers
+#define PG_DECL(S, M, D, T) void pgtt_launch_physics_s##S##_##M##_##D##_##T(int nblocks, hipStream_t st, const pgtt::KArgs& a, const float* action);
+#define PG_DECL8(S) PG_DECL(S, 0, 0, 0) PG_DECL(S, 0, 0, 1) PG_DECL(S, 0, 1, 0) PG_DECL(S, 0, 1, 1) PG_DECL(S, 1, 0, 0) PG_DECL(S, 1, 0, 1) PG_DECL(S, 1, 1, 0) PG_DECL(S, 1, 1, 1)
+PG_DECL8(1) PG_DECL8(4)
+#undef PG_DECL8
 #undef PG_DECL
 
 namespace {
@@ -45,6 +47,7 @@ struct pgtt_env {
   unsigned long long seed = 0;
   long long env_off = 0;
   bool timing = false;
+  bool hex = false;               // lane layout of physics_kernel: 4 envs per wave instead of 16
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool ev_valid = false;
 };
@@ -81,15 +84,16 @@ void launch_physics(pgtt_env* h, const pgtt::KArgs& a_in, const float* action, h
 #if defined(PGTT_TRACE) || defined(PGTT_TIME)
   a.trace = pgtt_trace_buffer() + 16384 * (g_trace_launch++ & 3);
 #endif
-  const int nb = (h->N + 15) / 16;                      // one env per quad of lanes: 16 envs per 64-thread block
+  // quad layout: 16 envs per 64-thread block; hex layout: 4 envs per block (pgtt_physics_quad.hip.h)
   const bool dr = h->buf.params != nullptr, terr = h->T > 0;
-  if (MODE == 0) {
-    if (dr && terr) pgtt_launch_physics_0_1_1(nb, st, a, action); else if (dr) pgtt_launch_physics_0_1_0(nb, st, a, action);
-    else if (terr) pgtt_launch_physics_0_0_1(nb, st, a, action); else pgtt_launch_physics_0_0_0(nb, st, a, action);
-  } else {
-    if (dr && terr) pgtt_launch_physics_1_1_1(nb, st, a, action); else if (dr) pgtt_launch_physics_1_1_0(nb, st, a, action);
-    else if (terr) pgtt_launch_physics_1_0_1(nb, st, a, action); else pgtt_launch_physics_1_0_0(nb, st, a, action);
-  }
+  typedef void (*launcher)(int, hipStream_t, const pgtt::KArgs&, const float*);
+  static const launcher table[2][2][2][2] = {
+      {{{pgtt_launch_physics_s1_0_0_0, pgtt_launch_physics_s1_0_0_1}, {pgtt_launch_physics_s1_0_1_0, pgtt_launch_physics_s1_0_1_1}},
+       {{pgtt_launch_physics_s1_1_0_0, pgtt_launch_physics_s1_1_0_1}, {pgtt_launch_physics_s1_1_1_0, pgtt_launch_physics_s1_1_1_1}}},
+      {{{pgtt_launch_physics_s4_0_0_0, pgtt_launch_physics_s4_0_0_1}, {pgtt_launch_physics_s4_0_1_0, pgtt_launch_physics_s4_0_1_1}},
+       {{pgtt_launch_physics_s4_1_0_0, pgtt_launch_physics_s4_1_0_1}, {pgtt_launch_physics_s4_1_1_0, pgtt_launch_physics_s4_1_1_1}}}};
+  const int per = h->hex ? 4 : 16;
+  table[h->hex ? 1 : 0][MODE][dr ? 1 : 0][terr ? 1 : 0]((h->N + per - 1) / per, st, a, action);
 }
 
 template <int OMODE>
@@ -141,6 +145,13 @@ int pgtt_create(const PgttConfig* cfg, const PgttModel* model, int device, int n
   HIP_TRY(hipSetDevice(device));
   pgtt_env* h = new pgtt_env();
   h->device = device; h->N = num_envs; h->cfg = *cfg; h->model = *model;
+  {
+    // lane layout: PGTT_LAYOUT=quad|hex forces one; default by batch size
+    const char* lay = getenv("PGTT_LAYOUT");
+    if (lay && !strcmp(lay, "hex")) h->hex = true;
+    else if (lay && !strcmp(lay, "quad")) h->hex = false;
+    else h->hex = false;
+  }
   HIP_TRY(hipMalloc(&h->d_cfg, sizeof(PgttConfig)));
   HIP_TRY(hipMalloc(&h->d_model, sizeof(PgttModel)));
   HIP_TRY(hipMemcpy(h->d_cfg, cfg, sizeof(PgttConfig), hipMemcpyHostToDevice));

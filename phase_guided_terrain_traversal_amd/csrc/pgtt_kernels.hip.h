@@ -65,13 +65,15 @@ PG_INL int xcd_block(int bid, int nblocks) {
   return (bid & 7) * (nblocks >> 3) + (bid >> 3);
 }
 
-// ------------------------------------------------------------------ physics: one env per QUAD of lanes (16 envs per wave)
-template <int MODE, bool HAS_DR, bool HAS_TERRAIN>
+// ------------------------------------------------------------------ physics: one env per 4 * SUBS lanes (layouts: see pgtt_physics_quad.hip.h)
+// SUBS is part of the kernel's name only (the layout itself is the translation unit's PG_SUBS).
+template <int MODE, bool HAS_DR, bool HAS_TERRAIN, int SUBS>
 __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __restrict__ action) {
+  static_assert(SUBS == kSubs, "one lane layout per translation unit");
   const int N = a.N;
-  const int l = threadIdx.x & 3;                       // leg FL,FR,RL,RR
+  const int l = (threadIdx.x / kSubs) & 3;             // leg FL,FR,RL,RR
   const int blk = xcd_block(blockIdx.x, gridDim.x);
-  int e = blk * 16 + (threadIdx.x >> 2);
+  int e = blk * kEnvsPerWave + (threadIdx.x / (4 * kSubs));
   bool valid = e < N;
   if (!valid) e = N - 1;                               // keep whole quads running (DPP), suppress the stores
   if (MODE != MODE_STEP && a.mask && !a.mask[e]) valid = false;
@@ -102,19 +104,19 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   int nbox = 0;
   // LDS staging of the env's terrain variant: centre + bounding radius of its <=100 boxes (read 2 x 4 substeps
   // by the broad phase), and a per-lane column for the broad-phase keys of the own foot
-  __shared__ float4 sh_box[HAS_TERRAIN ? PGTT_MAX_BOX * 16 : 1];      // (cx, cy, cz, hx)
-  __shared__ float2 sh_box2[HAS_TERRAIN ? PGTT_MAX_BOX * 16 : 1];     // (hy, hz)
+  __shared__ float4 sh_box[HAS_TERRAIN ? PGTT_MAX_BOX * kEnvsPerWave : 1];      // (cx, cy, cz, hx)
+  __shared__ float2 sh_box2[HAS_TERRAIN ? PGTT_MAX_BOX * kEnvsPerWave : 1];     // (hy, hz)
   __shared__ float sh_con[HAS_TERRAIN ? kMaxB * kSlotFields * 64 : 1];
-  const int quad = threadIdx.x >> 2;
+  const int quad = threadIdx.x / (4 * kSubs);          // env within the wave
   const BoxSlots slots{sh_con, (int)threadIdx.x};
   if (HAS_TERRAIN) {
     int v = a.buf.variant ? a.buf.variant[e] : 0;
     boxes = a.terrain + (long)v * a.B;
     nbox = a.B;
-    for (int b = l; b < nbox; b += 4) {
+    for (int b = threadIdx.x % (4 * kSubs); b < nbox; b += 4 * kSubs) {
       const TerrainBox* tb = boxes + b;
-      sh_box[b * 16 + quad] = make_float4(tb->px, tb->py, tb->pz, tb->hx);
-      sh_box2[b * 16 + quad] = make_float2(tb->hy, tb->hz);
+      sh_box[b * kEnvsPerWave + quad] = make_float4(tb->px, tb->py, tb->pz, tb->hx);
+      sh_box2[b * kEnvsPerWave + quad] = make_float2(tb->hy, tb->hz);
     }
     __syncthreads();
   }
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   QPhysics ph(m, em, s, l);
   QSolver sol(m, s, slots);
 #ifdef PGTT_TRACE
-  if (valid && e == 0 && a.trace) s.tr = a.trace + l;
+  if (valid && e == 0 && a.trace && threadIdx.x % kSubs == 0) s.tr = a.trace + l;
 #endif
   const int nsub = MODE == MODE_STEP ? cfg->n_substeps : 1;
   const float dt = m->timestep;

@@ -16,26 +16,71 @@
 
 namespace pgtt {
 
-// ------------------------------------------------------------------ quad cross-lane primitives (DPP, VALU only)
+// ------------------------------------------------------------------ cross-lane primitives (DPP, VALU only)
+// Two lane layouts share this file (compile-time PG_SUBS, one translation unit each):
+//   PG_SUBS = 1  "quad": lane = 4*env + leg                  16 envs per wave
+//   PG_SUBS = 4  "hex" : lane = 16*env + 4*leg + sub          4 envs per wave; the four SUB-lanes of a leg hold the
+//                       leg's state replicated (bit-identical) and split selected loops among themselves (constraint
+//                       rows of the line search / Hessian, boxes of the collision passes).  A launch lasts as long as
+//                       one wave's instruction stream, so for small batches the shorter stream wins.
+// "quad_*" primitives act over the four LEGS of an env, "sub_*" over the four sub-lanes of a leg.
+#ifndef PG_SUBS
+#define PG_SUBS 1
+#endif
+constexpr int kSubs = PG_SUBS;
+constexpr int kEnvsPerWave = 16 / PG_SUBS;
 template <int CTRL>
 PG_INL float dpp_f(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
 }
 template <int CTRL>
 PG_INL int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
-// The two butterfly adds must stay plain adds: with contraction on, `p*q + dpp(p*q)` may be fused into
+// The butterfly adds must stay plain adds: with contraction on, `p*q + dpp(p*q)` may be fused into
 // fma(p, q, dpp(round(p*q))), which differs between the two lanes of a pair and breaks the invariant that every
-// lane of a quad holds the bit-identical sum (base-body quantities are replicated, never broadcast).
+// lane of an env holds the bit-identical sum (base-body quantities are replicated, never broadcast).
+// Both steps pair lane i with a lane that computes the same two operands in the other order, so all lanes agree.
+#if PG_SUBS == 1
+constexpr int kLegStep1 = 0xB1, kLegStep2 = 0x4E;       // quad_perm [1,0,3,2], [2,3,0,1]
+#else
+constexpr int kLegStep1 = 0x128, kLegStep2 = 0x124;     // row_ror:8, row_ror:4 (legs are 4 lanes apart in a 16-lane row)
+#endif
 PG_INL float quad_sum(float x) {
+#pragma clang fp contract(off)
+  x = x + dpp_f<kLegStep1>(x);
+  x = x + dpp_f<kLegStep2>(x);
+  return x;
+}
+PG_INL int quad_sum_i(int x) { x += dpp_i<kLegStep1>(x); x += dpp_i<kLegStep2>(x); return x; }
+PG_INL V3 quad_sum(V3 a) { return v3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)); }
+// sum over the four sub-lanes of a leg (hex layout; identity in the quad layout)
+PG_INL float sub_sum(float x) {
+#if PG_SUBS == 4
 #pragma clang fp contract(off)
   x = x + dpp_f<0xB1>(x);
   x = x + dpp_f<0x4E>(x);
+#endif
   return x;
 }
-PG_INL int quad_sum_i(int x) { x += dpp_i<0xB1>(x); x += dpp_i<0x4E>(x); return x; }
-PG_INL V3 quad_sum(V3 a) { return v3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)); }
+PG_INL unsigned sub_or(unsigned x) {
+#if PG_SUBS == 4
+  x |= (unsigned)dpp_i<0xB1>((int)x);
+  x |= (unsigned)dpp_i<0x4E>((int)x);
+#endif
+  return x;
+}
+// value held by leg J (same sub-lane)
+#if PG_SUBS == 1
 template <int J> PG_INL float quad_bcast(float x) { return dpp_f<J * 0x55>(x); }
 template <int J> PG_INL int quad_bcast(int x) { return dpp_i<J * 0x55>(x); }
+#else
+// row_ror:4k hands lane i the value of lane i - 4k, i.e. of leg (own - k) & 3
+template <int J> PG_INL int quad_bcast(int x) {
+  const int k = ((int)(threadIdx.x >> 2) - J) & 3;
+  const int r1 = dpp_i<0x124>(x), r2 = dpp_i<0x128>(x), r3 = dpp_i<0x12C>(x);
+  return k == 0 ? x : (k == 1 ? r1 : (k == 2 ? r2 : r3));
+}
+template <int J> PG_INL float quad_bcast(float x) { return __int_as_float(quad_bcast<J>(__float_as_int(x))); }
+#endif
 
 constexpr int kMaxB = 4;          // box contacts one foot can hold (= max_contact_points of the reference)
 constexpr int kMaxPenQ = 4;       // penetrating (foot, box) pairs tracked per foot
@@ -558,8 +603,8 @@ struct QPhysics {
 #pragma unroll
           for (int j = 0; j < 8; j++) {
             const int b = w * 32 + j0 + j < PGTT_MAX_BOX ? w * 32 + j0 + j : PGTT_MAX_BOX - 1;
-            const float4 A = sh_box[b * 16 + quad];
-            const float2 H2 = sh_box2[b * 16 + quad];
+            const float4 A = sh_box[b * kEnvsPerWave + quad];
+            const float2 H2 = sh_box2[b * kEnvsPerWave + quad];
             const float ex = fabsf(A.x - fx) - A.w, ey = fabsf(A.y - fy) - H2.x, ez = fabsf(A.z - fz) - H2.y;
             const float t = fmaxf(fmaxf(ex, ey), ez) - pad;
             byte |= (__float_as_uint(t) >> 31) << j;
@@ -624,7 +669,7 @@ struct QPhysics {
       int cnt = 0;
 #pragma unroll 4
       for (int b = 0; b < nbox; b++) {
-        const float4 A = sh_box[b * 16 + quad];
+        const float4 A = sh_box[b * kEnvsPerWave + quad];
         V3 dv = v3(A.x, A.y, A.z) - s.footc;
         cnt += dot(dv, dv) <= thr2 ? 1 : 0;
       }
@@ -635,7 +680,7 @@ struct QPhysics {
       // every lane counts over its own foot's pairs, the quad sum gives the rank
 #pragma unroll 4
       for (int b = 0; b < nbox; b++) {
-        const float4 A = sh_box[b * 16 + quad];
+        const float4 A = sh_box[b * kEnvsPerWave + quad];
         float key = norm(v3(A.x, A.y, A.z) - s.footc) - keyC;
         int idx = l * nbox + b;
 #pragma unroll
