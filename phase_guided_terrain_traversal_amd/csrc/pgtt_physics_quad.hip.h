@@ -954,25 +954,45 @@ struct QSolver {
     f2 q[NA][3];
 #pragma unroll
     for (int a = 0; a < NA; a++) { q[a][0] = f2{0.f, 0.f}; q[a][1] = f2{0.f, 0.f}; q[a][2] = f2{0.f, 0.f}; }
-    if (any_lim) {
-      // the three limit rows have their own D each: pairs (row0, row1) and (row2, empty)
-      const f2 ja01{jar_lim[0], jar_lim[1]}, jv01{jv_lim[0], jv_lim[1]}, D01{s.lim_D[0], s.lim_D[1]};
-      const f2 ja2{jar_lim[2], 0.f}, jv2{jv_lim[2], 0.f}, D2{s.lim_D[2], 0.f};
-      ls_row2d<NA>(ja01, jv01, D01, al, q);
-      ls_row2d<NA>(ja2, jv2, D2, al, q);
-    }
-    if (any_con0) {
-      ls_row2<NA>(f2{jar0[0], jar0[1]}, f2{jv0[0], jv0[1]}, s.con0.D, al, q);
-      ls_row2<NA>(f2{jar0[2], jar0[3]}, f2{jv0[2], jv0[3]}, s.con0.D, al, q);
-    }
-    for (int k = 0; k < nslots; k++) {
-      const float Dk = slots.at(k, 2);
-      ls_row2<NA>(f2{slots.jar(k, 0), slots.jar(k, 1)}, f2{slots.jv(k, 0), slots.jv(k, 1)}, Dk, al, q);
-      ls_row2<NA>(f2{slots.jar(k, 2), slots.jar(k, 3)}, f2{slots.jv(k, 2), slots.jv(k, 3)}, Dk, al, q);
+    if (kSubs == 1) {
+      if (any_lim) {
+        // the three limit rows have their own D each: pairs (row0, row1) and (row2, empty)
+        const f2 ja01{jar_lim[0], jar_lim[1]}, jv01{jv_lim[0], jv_lim[1]}, D01{s.lim_D[0], s.lim_D[1]};
+        const f2 ja2{jar_lim[2], 0.f}, jv2{jv_lim[2], 0.f}, D2{s.lim_D[2], 0.f};
+        ls_row2d<NA>(ja01, jv01, D01, al, q);
+        ls_row2d<NA>(ja2, jv2, D2, al, q);
+      }
+      if (any_con0) {
+        ls_row2<NA>(f2{jar0[0], jar0[1]}, f2{jv0[0], jv0[1]}, s.con0.D, al, q);
+        ls_row2<NA>(f2{jar0[2], jar0[3]}, f2{jv0[2], jv0[3]}, s.con0.D, al, q);
+      }
+      for (int k = 0; k < nslots; k++) {
+        const float Dk = slots.at(k, 2);
+        ls_row2<NA>(f2{slots.jar(k, 0), slots.jar(k, 1)}, f2{slots.jv(k, 0), slots.jv(k, 1)}, Dk, al, q);
+        ls_row2<NA>(f2{slots.jar(k, 2), slots.jar(k, 3)}, f2{slots.jv(k, 2), slots.jv(k, 3)}, Dk, al, q);
+      }
+    } else {
+      // hex layout: sub-lane r evaluates row r of every constraint of its leg (limit row r < 3, pyramid row r of the
+      // plane contact and of each box slot); the sums below run over all 16 lanes of the env
+      const int r = threadIdx.x & 3;
+      if (any_lim || any_con0) {
+        const f2 ja{sel4(r, jar_lim[0], jar_lim[1], jar_lim[2], 0.f), sel4(r, jar0[0], jar0[1], jar0[2], jar0[3])};
+        const f2 jv{sel4(r, jv_lim[0], jv_lim[1], jv_lim[2], 0.f), sel4(r, jv0[0], jv0[1], jv0[2], jv0[3])};
+        const f2 D{sel4(r, s.lim_D[0], s.lim_D[1], s.lim_D[2], 0.f), s.con0.D};
+        ls_row2d<NA>(ja, jv, D, al, q);
+      }
+      for (int k = 0; k < nslots; k += 2) {
+        const bool two = k + 1 < nslots;
+        const int k1 = two ? k + 1 : k;
+        const f2 ja{slots.jar(k, r), two ? slots.jar(k1, r) : 0.f}, jv{slots.jv(k, r), two ? slots.jv(k1, r) : 0.f};
+        const f2 D{slots.at(k, 2), two ? slots.at(k1, 2) : 0.f};
+        ls_row2d<NA>(ja, jv, D, al, q);
+      }
     }
 #pragma unroll
     for (int a = 0; a < NA; a++) {
-      const float q0 = quad_sum(q[a][0].x + q[a][0].y) + qg0, q1 = quad_sum(q[a][1].x + q[a][1].y) + qg1, q2 = quad_sum(q[a][2].x + q[a][2].y) + qg2;
+      const float q0 = quad_sum(sub_sum(q[a][0].x + q[a][0].y)) + qg0, q1 = quad_sum(sub_sum(q[a][1].x + q[a][1].y)) + qg1,
+                  q2 = quad_sum(sub_sum(q[a][2].x + q[a][2].y)) + qg2;
       const float alpha = al[a];
       out[a].alpha = alpha;
       out[a].cost = alpha * alpha * q2 + alpha * q1 + q0;
@@ -1029,8 +1049,24 @@ struct QSolver {
 #pragma unroll
     for (int k = 0; k < 3; k++) { al += sl[k] * Mal[k]; bl += sl[k] * s.qfs_l[k]; el += sl[k] * mvl[k]; }
     const float qg0 = gauss, qg1 = (ab + quad_sum(al)) - (bb_ + quad_sum(bl)), qg2 = 0.5f * (eb + quad_sum(el));
-    auto in_bracket = [](const LSPoint& x, const LSPoint& y) {
-      return ((x.d0 < y.d0) && (y.d0 < 0.f)) || ((x.d0 > y.d0) && (y.d0 > 0.f));
+    // Bracket update (mjx solver._update_bracket): a candidate y replaces the bracket end x when
+    //   in_bracket(x, y) = (x.d0 < y.d0 < 0) or (x.d0 > y.d0 > 0),
+    // tried in a fixed order, each test against the already updated end.  With u = d0 * sign(x.d0) (exact) this is a
+    // running "0 < u_y < u_x": a chain over ONE scalar; the winner's four fields are picked once at the end.
+    auto tighten = [](const LSPoint& x, const LSPoint& c1, const LSPoint& c2, const LSPoint& c3, bool& moved) {
+      const float sg = x.d0 > 0.f ? 1.0f : -1.0f;
+      float u = x.d0 * sg;                          // |x.d0| (0 if x.d0 == 0: nothing can enter the bracket)
+      const float u1 = c1.d0 * sg, u2 = c2.d0 * sg, u3 = c3.d0 * sg;
+      const bool k1 = (u1 > 0.f) & (u1 < u); u = k1 ? u1 : u;
+      const bool k2 = (u2 > 0.f) & (u2 < u); u = k2 ? u2 : u;
+      const bool k3 = (u3 > 0.f) & (u3 < u);
+      moved = k1 | k2 | k3;
+      LSPoint r;
+      r.alpha = k3 ? c3.alpha : (k2 ? c2.alpha : (k1 ? c1.alpha : x.alpha));
+      r.cost = k3 ? c3.cost : (k2 ? c2.cost : (k1 ? c1.cost : x.cost));
+      r.d0 = k3 ? c3.d0 : (k2 ? c2.d0 : (k1 ? c1.d0 : x.d0));
+      r.d1 = k3 ? c3.d1 : (k2 ? c2.d1 : (k1 ? c1.d1 : x.d1));
+      return r;
     };
     LSPoint p0, lo0;
     { const float a0 = 0.f; ls_points<1>(&a0, jv_lim, jv0, qg0, qg1, qg2, &p0); }
@@ -1044,14 +1080,10 @@ struct QSolver {
       const float al3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha)};
       LSPoint pt[3];
       ls_points<3>(al3, jv_lim, jv0, qg0, qg1, qg2, pt);
-      LSPoint nlo = lo, nhi = hi;
-      bool s1 = in_bracket(nlo, pt[0]); if (s1) nlo = pt[0];
-      bool s2 = in_bracket(nlo, pt[2]); if (s2) nlo = pt[2];
-      bool s3 = in_bracket(nlo, pt[1]); if (s3) nlo = pt[1];
-      bool t1 = in_bracket(nhi, pt[1]); if (t1) nhi = pt[1];
-      bool t2 = in_bracket(nhi, pt[2]); if (t2) nhi = pt[2];
-      bool t3 = in_bracket(nhi, pt[0]); if (t3) nhi = pt[0];
-      if (!done) { lo = nlo; hi = nhi; swap = s1 | s2 | s3 | t1 | t2 | t3; it++; }
+      bool ml, mh;
+      const LSPoint nlo = tighten(lo, pt[0], pt[2], pt[1], ml);
+      const LSPoint nhi = tighten(hi, pt[1], pt[2], pt[0], mh);
+      if (!done) { lo = nlo; hi = nhi; swap = ml | mh; it++; }
     }
     bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
     float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
