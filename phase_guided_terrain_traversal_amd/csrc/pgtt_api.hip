@@ -47,7 +47,7 @@ struct pgtt_env {
   unsigned long long seed = 0;
   long long env_off = 0;
   bool timing = false;
-  bool hex = false;               // lane layout of physics_kernel: 4 envs per wave instead of 16
+  int layout = 0;                 // lane layout of physics_kernel: 1 quad (16 envs per wave), 4 hex (4 envs per wave), 0 auto
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool ev_valid = false;
 };
@@ -92,8 +92,11 @@ void launch_physics(pgtt_env* h, const pgtt::KArgs& a_in, const float* action, h
        {{pgtt_launch_physics_s1_1_0_0, pgtt_launch_physics_s1_1_0_1}, {pgtt_launch_physics_s1_1_1_0, pgtt_launch_physics_s1_1_1_1}}},
       {{{pgtt_launch_physics_s4_0_0_0, pgtt_launch_physics_s4_0_0_1}, {pgtt_launch_physics_s4_0_1_0, pgtt_launch_physics_s4_0_1_1}},
        {{pgtt_launch_physics_s4_1_0_0, pgtt_launch_physics_s4_1_0_1}, {pgtt_launch_physics_s4_1_1_0, pgtt_launch_physics_s4_1_1_1}}}};
-  const int per = h->hex ? 4 : 16;
-  table[h->hex ? 1 : 0][MODE][dr ? 1 : 0][terr ? 1 : 0]((h->N + per - 1) / per, st, a, action);
+  // auto: the hex layout has the shorter instruction stream on box terrain (line-search rows and collision passes are
+  // split over the sub-lanes) but four times the waves; it wins while those still run concurrently (<= 1024 waves)
+  const bool hex = h->layout == 4 || (h->layout == 0 && terr && h->N <= 4096);
+  const int per = hex ? 4 : 16;
+  table[hex ? 1 : 0][MODE][dr ? 1 : 0][terr ? 1 : 0]((h->N + per - 1) / per, st, a, action);
 }
 
 template <int OMODE>
@@ -148,9 +151,7 @@ int pgtt_create(const PgttConfig* cfg, const PgttModel* model, int device, int n
   {
     // lane layout: PGTT_LAYOUT=quad|hex forces one; default by batch size
     const char* lay = getenv("PGTT_LAYOUT");
-    if (lay && !strcmp(lay, "hex")) h->hex = true;
-    else if (lay && !strcmp(lay, "quad")) h->hex = false;
-    else h->hex = false;
+    h->layout = (lay && !strcmp(lay, "hex")) ? 4 : ((lay && !strcmp(lay, "quad")) ? 1 : 0);
   }
   HIP_TRY(hipMalloc(&h->d_cfg, sizeof(PgttConfig)));
   HIP_TRY(hipMalloc(&h->d_model, sizeof(PgttModel)));

@@ -61,6 +61,16 @@ PG_INL float sub_sum(float x) {
 #endif
   return x;
 }
+PG_INL int sub_sum_i(int x) {
+#if PG_SUBS == 4
+  x += dpp_i<0xB1>(x);
+  x += dpp_i<0x4E>(x);
+#endif
+  return x;
+}
+// value held by sub-lane Q of the own leg (hex layout)
+template <int Q> PG_INL int sub_bcast(int x) { return PG_SUBS == 4 ? dpp_i<Q * 0x55>(x) : x; }
+template <int Q> PG_INL float sub_bcast(float x) { return PG_SUBS == 4 ? dpp_f<Q * 0x55>(x) : x; }
 PG_INL unsigned sub_or(unsigned x) {
 #if PG_SUBS == 4
   x |= (unsigned)dpp_i<0xB1>((int)x);
@@ -589,30 +599,53 @@ struct QPhysics {
     {
       const float pad = rad + 1e-5f;
       const float fx = s.footc.x, fy = s.footc.y, fz = s.footc.z;
+      if (kSubs == 1) {
 #pragma unroll
-      for (int w = 0; w < 4; w++) {
-        if (w * 32 >= nbox) break;                          // nbox is wave-uniform
-        unsigned bits = 0u;
-        const int left = nbox - w * 32 < 32 ? nbox - w * 32 : 32;   // valid boxes in this word (wave-uniform)
-        // batches of 8 boxes: enough LDS reads in flight, few enough not to be spilled.  The outcome is taken from
-        // the SIGN BIT of max_i(|d_i| - h_i) - pad (no compare -> no SGPR mask per box); `<` instead of `<=` is still
-        // a superset of the penetrating boxes (penetration needs |d_i| < h_i + rad < h_i + pad).  Rows >= nbox of
-        // the LDS tables are allocated but stale: the last batch may read them, their bits are cleared.
-        for (int j0 = 0; j0 < left; j0 += 8) {
-          unsigned byte = 0u;
+        for (int w = 0; w < 4; w++) {
+          if (w * 32 >= nbox) break;                          // nbox is wave-uniform
+          unsigned bits = 0u;
+          const int left = nbox - w * 32 < 32 ? nbox - w * 32 : 32;   // valid boxes in this word (wave-uniform)
+          // batches of 8 boxes: enough LDS reads in flight, few enough not to be spilled.  The outcome is taken from
+          // the SIGN BIT of max_i(|d_i| - h_i) - pad (no compare -> no SGPR mask per box); `<` instead of `<=` is still
+          // a superset of the penetrating boxes (penetration needs |d_i| < h_i + rad < h_i + pad).  Rows >= nbox of
+          // the LDS tables are allocated but stale: the last batch may read them, their bits are cleared.
+          for (int j0 = 0; j0 < left; j0 += 8) {
+            unsigned byte = 0u;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const int b = w * 32 + j0 + j < PGTT_MAX_BOX ? w * 32 + j0 + j : PGTT_MAX_BOX - 1;
+              const float4 A = sh_box[b * kEnvsPerWave + quad];
+              const float2 H2 = sh_box2[b * kEnvsPerWave + quad];
+              const float ex = fabsf(A.x - fx) - A.w, ey = fabsf(A.y - fy) - H2.x, ez = fabsf(A.z - fz) - H2.y;
+              const float t = fmaxf(fmaxf(ex, ey), ez) - pad;
+              byte |= (__float_as_uint(t) >> 31) << j;
+            }
+            bits |= byte << j0;
+          }
+          if (left < 32) bits &= (1u << left) - 1u;
+          cm[w] = bits;
+        }
+      } else {
+        // hex layout: the boxes go round the four sub-lanes of the leg (box 32w + 4j + sub -> bit 4j + sub of word w:
+        // neighbouring sub-lanes read neighbouring LDS rows, no bank conflicts); an OR over the sub-lanes gives every
+        // lane the full mask
+        const int r = threadIdx.x & 3;
+#pragma unroll 1
+        for (int w = 0; w * 32 < nbox; w++) {               // nbox is wave-uniform; one batch of 8 LDS rows in flight
+          unsigned bits = 0u;
 #pragma unroll
           for (int j = 0; j < 8; j++) {
-            const int b = w * 32 + j0 + j < PGTT_MAX_BOX ? w * 32 + j0 + j : PGTT_MAX_BOX - 1;
+            const int bx = w * 32 + 4 * j + r;
+            const int b = bx < PGTT_MAX_BOX ? bx : PGTT_MAX_BOX - 1;
             const float4 A = sh_box[b * kEnvsPerWave + quad];
             const float2 H2 = sh_box2[b * kEnvsPerWave + quad];
             const float ex = fabsf(A.x - fx) - A.w, ey = fabsf(A.y - fy) - H2.x, ez = fabsf(A.z - fz) - H2.y;
             const float t = fmaxf(fmaxf(ex, ey), ez) - pad;
-            byte |= (__float_as_uint(t) >> 31) << j;
+            bits |= (bx < nbox ? (__float_as_uint(t) >> 31) : 0u) << (4 * j);
           }
-          bits |= byte << j0;
+          const unsigned v = sub_or(bits << r);
+          cm[0] = w == 0 ? v : cm[0]; cm[1] = w == 1 ? v : cm[1]; cm[2] = w == 2 ? v : cm[2]; cm[3] = w == 3 ? v : cm[3];
         }
-        if (left < 32) bits &= (1u << left) - 1u;
-        cm[w] = bits;
       }
     }
     PG_TICK(s, 12);
@@ -620,24 +653,49 @@ struct QPhysics {
     QPen pen[kMaxPenQ]; int npen = 0;
 #pragma unroll
     for (int i = 0; i < kMaxPenQ; i++) { pen[i].dist = 1.f; pen[i].key = 3.0e38f; pen[i].idx = 0x7fffffff; pen[i].pos = v3(0, 0, 0); pen[i].n = v3(0, 0, 1); }
-    for (;;) {
+    // lowest set bit of the 128-bit mask (-1 if empty), cleared
+    auto pop = [&]() {
       const bool have = (cm[0] | cm[1] | cm[2] | cm[3]) != 0u;
-      if (__ballot(have) == 0ull) break;
-      // lowest set bit of the 128-bit mask
       const int w = cm[0] ? 0 : (cm[1] ? 1 : (cm[2] ? 2 : 3));
       const unsigned word = w == 0 ? cm[0] : (w == 1 ? cm[1] : (w == 2 ? cm[2] : cm[3]));
       const int bit = have ? (__ffs(word) - 1) : 0;
       const unsigned clr = have ? ~(1u << bit) : ~0u;
       cm[0] &= w == 0 ? clr : ~0u; cm[1] &= w == 1 ? clr : ~0u; cm[2] &= w == 2 ? clr : ~0u; cm[3] &= w == 3 ? clr : ~0u;
-      const int b = have ? w * 32 + bit : 0;
-      TerrainBox tb = boxes[b];
-      float nd; V3 pw, nw;
-      sphere_box(s.footc, rad, tb, nd, pw, nw);
-      if (have && nd < 0.f && npen < kMaxPenQ) {
-        QPen pp; pp.dist = nd; pp.key = norm(v3(tb.px, tb.py, tb.pz) - s.footc) - keyC; pp.idx = l * nbox + b; pp.pos = pw; pp.n = nw;
+      return have ? w * 32 + bit : -1;
+    };
+    auto keep = [&](const QPen& pp) {
+      if (pp.dist < 0.f && npen < kMaxPenQ) {
 #pragma unroll
         for (int i = 0; i < kMaxPenQ; i++) if (i == npen) pen[i] = pp;
         npen++;
+      }
+    };
+    for (;;) {
+      if (__ballot((cm[0] | cm[1] | cm[2] | cm[3]) != 0u) == 0ull) break;
+      int b;
+      if (kSubs == 1) {
+        b = pop();
+      } else {
+        // hex layout: the next four candidates go to the four sub-lanes (the mask is replicated, so every sub-lane pops
+        // all four and keeps its own)
+        const int r = threadIdx.x & 3;
+        const int b0 = pop(), b1 = pop(), b2 = pop(), b3 = pop();
+        b = r == 0 ? b0 : (r == 1 ? b1 : (r == 2 ? b2 : b3));
+      }
+      const bool have = b >= 0;
+      TerrainBox tb = boxes[have ? b : 0];
+      float nd; V3 pw, nw;
+      sphere_box(s.footc, rad, tb, nd, pw, nw);
+      QPen pp; pp.dist = have ? nd : 1.f; pp.key = norm(v3(tb.px, tb.py, tb.pz) - s.footc) - keyC; pp.idx = l * nbox + (have ? b : 0); pp.pos = pw; pp.n = nw;
+      if (kSubs == 1) {
+        keep(pp);
+      } else {
+        // every lane appends the four results in candidate (= box index) order, as the sequential loop would
+#define PG_TAKE(Q) { QPen g; g.dist = sub_bcast<Q>(pp.dist); g.key = sub_bcast<Q>(pp.key); g.idx = sub_bcast<Q>(pp.idx); \
+                     g.pos = v3(sub_bcast<Q>(pp.pos.x), sub_bcast<Q>(pp.pos.y), sub_bcast<Q>(pp.pos.z));               \
+                     g.n = v3(sub_bcast<Q>(pp.n.x), sub_bcast<Q>(pp.n.y), sub_bcast<Q>(pp.n.z)); keep(g); }
+        PG_TAKE(0) PG_TAKE(1) PG_TAKE(2) PG_TAKE(3)
+#undef PG_TAKE
       }
     }
     PG_TICK(s, 13);
@@ -668,12 +726,12 @@ struct QPhysics {
       const float thr = (kmax + keyC) * 1.000002f + 1e-7f, thr2 = kmax > -1.0e38f ? thr * thr : -1.f;
       int cnt = 0;
 #pragma unroll 4
-      for (int b = 0; b < nbox; b++) {
+      for (int b = (kSubs == 1 ? 0 : (int)(threadIdx.x & 3)); b < nbox; b += kSubs) {     // hex: boxes go round the sub-lanes
         const float4 A = sh_box[b * kEnvsPerWave + quad];
         V3 dv = v3(A.x, A.y, A.z) - s.footc;
         cnt += dot(dv, dv) <= thr2 ? 1 : 0;
       }
-      need_exact = quad_sum_i(cnt) > maxp;
+      need_exact = quad_sum_i(sub_sum_i(cnt)) > maxp;
     }
     if (broad && __ballot(need_exact) != 0ull) {
       // pass 2b (rare): exact broad-phase rank = number of the 400 (foot, box) pairs that sort before the candidate;

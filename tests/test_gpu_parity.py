@@ -166,22 +166,29 @@ def run_parity(task, n, terrain, steps, dr=False, autoreset=False, noise=1.0, me
     return stats
 
 
-def test_flat_parity():
+def test_flat_parity(layout):
     st = run_parity("flat_terrain", 256, None, steps=40)
     assert st["active_contacts"] > 1000
 
 
-def test_level4_parity():
+@pytest.fixture(params=["quad", "hex"])
+def layout(request, monkeypatch):
+    """both lane layouts of physics_kernel (pgtt_physics_quad.hip.h): 16 or 4 envs per wave"""
+    monkeypatch.setenv("PGTT_LAYOUT", request.param)
+    return request.param
+
+
+def test_level4_parity(layout):
     terrain = np.load(os.path.join(ASSETS, "terrains", "level4.npy"))
     st = run_parity("stairs", 256, terrain, steps=60)
 
 
-def test_level13_dr_autoreset_parity():
+def test_level13_dr_autoreset_parity(layout):
     terrain = np.load(os.path.join(ASSETS, "terrains", "level13.npy"))
     run_parity("stairs", 128, terrain, steps=40, dr=True, autoreset=True)
 
 
-def test_ragged_env_counts_parity():
+def test_ragged_env_counts_parity(layout):
     """env counts that are not multiples of the 16 envs of a wave (partial last wave, grid not a multiple of the 8
     XCDs, a single partial wave) go through the same parity bar"""
     terrain = np.load(os.path.join(ASSETS, "terrains", "level4.npy"))
@@ -233,7 +240,7 @@ def dense_terrain():
     return np.asarray(T, dtype=np.float32)
 
 
-def test_broadphase_truncation_parity():
+def test_broadphase_truncation_parity(layout):
     terrain = dense_terrain()
     st = run_parity("stairs", 128, terrain, steps=25)
     assert st["box_contacts"] > 500
