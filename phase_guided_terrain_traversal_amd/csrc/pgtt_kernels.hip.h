@@ -146,6 +146,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
     const bool last = sub == nsub - 1;
     if (last) {
       float* __restrict__ Fr = a.buf.frame;
+      int ee = e; asm volatile("" : "+v"(ee));     // re-form the row addresses here (see the final stores)
       V3 w = s.cvel0.a, vl = s.cvel0.l;
       V3 dif = s.imu - s.com;
       V3 gyro = mtmul(s.R0, w);
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
         accA[0][k] = ct.x; accA[1][k] = ct.y; accA[2][k] = ct.z;
         accA[0][3 + k] = cr.x; accA[1][3 + k] = cr.y; accA[2][3 + k] = cr.z;
       }
-      auto put3 = [&](int row, V3 v) { Fr[row * (long)N + e] = v.x; Fr[(row + 1) * (long)N + e] = v.y; Fr[(row + 2) * (long)N + e] = v.z; };
+      auto put3 = [&](int row, V3 v) { Fr[row * (long)N + ee] = v.x; Fr[(row + 1) * (long)N + ee] = v.y; Fr[(row + 2) * (long)N + ee] = v.z; };
       if (lead) {
         put3(PGTT_F_GYRO, gyro); put3(PGTT_F_GLOBAL_LINVEL, glin); put3(PGTT_F_GLOBAL_ANGVEL, w); put3(PGTT_F_LOCAL_LINVEL, llin);
         put3(PGTT_F_UPVECTOR, v3(s.R0.m[2], s.R0.m[5], s.R0.m[8]));
@@ -183,12 +184,12 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
         put3(PGTT_F_FEET_POS + 3 * f, mtmul(s.R0, s.sitef - s.imu));
         S6 cv = s.cvell[2];
         put3(PGTT_F_FEET_VEL + 3 * f, cv.l - cross(s.sitef - s.com, cv.a));
-        Fr[(PGTT_F_CONTACT + f) * (long)N + e] = touching ? 1.0f : 0.0f;
-        Fr[(PGTT_F_FOOT_SITE_Z + f) * (long)N + e] = s.sitef.z;
+        Fr[(PGTT_F_CONTACT + f) * (long)N + ee] = touching ? 1.0f : 0.0f;
+        Fr[(PGTT_F_FOOT_SITE_Z + f) * (long)N + ee] = s.sitef.z;
 #pragma unroll
-        for (int k = 0; k < 3; k++) Fr[(PGTT_F_ACT_FORCE + 3 * f + k) * (long)N + e] = s.act_force[k];
+        for (int k = 0; k < 3; k++) Fr[(PGTT_F_ACT_FORCE + 3 * f + k) * (long)N + ee] = s.act_force[k];
         if (a.buf.dbg_contact && a.buf.dbg_dist) {
-          int* dc = a.buf.dbg_contact + (long)e * 16; float* dd = a.buf.dbg_dist + (long)e * 8;
+          int* dc = a.buf.dbg_contact + (long)ee * 16; float* dd = a.buf.dbg_dist + (long)ee * 8;
           dc[2 * l] = l; dc[2 * l + 1] = -1; dd[l] = s.con0.dist;
           if (HAS_TERRAIN) {
 #pragma unroll
@@ -203,14 +204,15 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
     sol.solve();
     if (last && lead) {
       float* __restrict__ Fr = a.buf.frame;
+      int ee = e; asm volatile("" : "+v"(ee));
 #pragma unroll
       for (int r = 0; r < 3; r++) {
         float v = acc0[r];
 #pragma unroll
         for (int k = 0; k < 6; k++) v += accA[r][k] * s.qacc_b[k];
-        Fr[(PGTT_F_ACCEL + r) * (long)N + e] = v;
+        Fr[(PGTT_F_ACCEL + r) * (long)N + ee] = v;
       }
-      if (a.buf.dbg_niter) a.buf.dbg_niter[e] = s.niter_max;
+      if (a.buf.dbg_niter) a.buf.dbg_niter[ee] = s.niter_max;
     }
     if (MODE == MODE_STEP) {
       // ---- semi-implicit Euler (eulerdamp disabled)
@@ -242,6 +244,9 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   }
 #endif
   if (!valid) return;
+  // The compiler would otherwise keep the ~50 row addresses formed for the loads at the top alive (spilled to scratch)
+  // until these stores: an opaque copy of the env index makes it re-form them here (one mad each).
+  asm volatile("" : "+v"(e));
   if (MODE == MODE_STEP || a.write_qpos) {
 #pragma unroll
     for (int i = 0; i < 7; i++) S[(PGTT_S_QPOS + i) * (long)N + e] = s.qb[i];
