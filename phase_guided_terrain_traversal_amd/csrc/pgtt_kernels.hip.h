@@ -106,9 +106,9 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   // by the broad phase), and a per-lane column for the broad-phase keys of the own foot
   __shared__ float4 sh_box[HAS_TERRAIN ? PGTT_MAX_BOX * kEnvsPerWave : 1];      // (cx, cy, cz, hx)
   __shared__ float2 sh_box2[HAS_TERRAIN ? PGTT_MAX_BOX * kEnvsPerWave : 1];     // (hy, hz)
-  __shared__ float sh_con[HAS_TERRAIN ? kMaxB * kSlotFields * 64 : 1];
+  __shared__ float sh_con[HAS_TERRAIN ? kMaxB * kSlotFields * kSlotCols : 1];
   const int quad = threadIdx.x / (4 * kSubs);          // env within the wave
-  const BoxSlots slots{sh_con, (int)threadIdx.x};
+  const BoxSlots slots{sh_con, (int)threadIdx.x / kSubs};
   if (HAS_TERRAIN) {
     int v = a.buf.variant ? a.buf.variant[e] : 0;
     boxes = a.terrain + (long)v * a.B;

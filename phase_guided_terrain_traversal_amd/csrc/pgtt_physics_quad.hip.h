@@ -78,6 +78,10 @@ PG_INL unsigned sub_or(unsigned x) {
 #endif
   return x;
 }
+// hex layout: sub-lane k of a leg OWNS box slot k of that leg: it alone completes the slot's record, forms its Jacobian
+// products and its force / Hessian contributions (summed over the sub-lanes afterwards), so that this work does not
+// grow with the number of slots in use; in the quad layout every lane owns all its slots.
+PG_INL bool owns_slot(int k) { return PG_SUBS == 1 || (int)(threadIdx.x & 3) == k; }
 // value held by leg J (same sub-lane)
 #if PG_SUBS == 1
 template <int J> PG_INL float quad_bcast(float x) { return dpp_f<J * 0x55>(x); }
@@ -109,13 +113,16 @@ struct QContact {
 // A contact Jacobian row is fr[a] . (V + W x off) where (W, V) is the calf's spatial motion: J itself (3x9) is
 // never stored; J x, J^T f and J^T W J are formed from (off, fr) and the leg's cdofs.
 
-// Box-contact records of the own foot live in LDS, one column per lane: field f of slot k at
-// sh[(k*kSlotFields + f)*64 + lane] (bank = lane: conflict-free).  This keeps the Newton loop's register
-// footprint independent of the number of box slots and lets the slot loops be real (wave-uniform) loops.
+// Box-contact records of the own foot live in LDS, one column per LEG (= per lane in the quad layout; shared by the four
+// sub-lanes of the leg in the hex layout): field f of slot k at sh[(k*kSlotFields + f)*kSlotCols + col] (consecutive
+// columns -> consecutive banks).  This keeps the Newton loop's register footprint independent of the number of box
+// slots and lets the slot loops be real (wave-uniform) loops; in the hex layout it is also how the sub-lane that owns a
+// slot hands its rows to the sub-lanes that own the rows (LDS accesses of one wave complete in program order).
 constexpr int kSlotFields = 29;   // dist mu D aref[4] off[3] fr[9] flags box | jar[4] jv[4]
+constexpr int kSlotCols = 64 / PG_SUBS;
 struct BoxSlots {
-  float* sh; int lane;
-  PG_INL float& at(int k, int f) const { return sh[(k * kSlotFields + f) * 64 + lane]; }
+  float* sh; int lane;            // lane = column = leg index within the wave
+  PG_INL float& at(int k, int f) const { return sh[(k * kSlotFields + f) * kSlotCols + lane]; }
   PG_INL void store(int k, const QContact& c) const {
     at(k, 0) = c.dist; at(k, 1) = c.mu; at(k, 2) = c.D;
 #pragma unroll
@@ -560,7 +567,8 @@ struct QPhysics {
     mix(m->foot_solref, m->foot_solimp, m->foot_solmix, m->box_solref, m->box_solimp, m->box_solmix, sr, si);
     float margin = fmaxf(m->foot_margin, m->box_margin) - fmaxf(m->foot_gap, m->box_gap);
 #pragma unroll
-    for (int k = 0; k < kMaxB; k++) {
+    for (int k0 = 0; k0 < (kSubs == 1 ? kMaxB : 1); k0++) {
+      const int k = kSubs == 1 ? k0 : (int)(threadIdx.x & 3);        // hex: sub-lane k completes slot k, in one pass
       if (__ballot(k < s.nbox) == 0ull) break;
       if (k < s.nbox) {
         QContact cc;
@@ -861,7 +869,9 @@ struct QSolver {
 #pragma unroll
       for (int r = 0; r < 4; r++) jar0[r] = (s.con0.row_active ? jx[r] : 0.f) - s.con0.aref[r];
     }
-    for (int k = 0; k < nslots; k++) {
+    for (int k0 = 0; k0 < (kSubs == 1 ? nslots : (nslots > 0 ? 1 : 0)); k0++) {
+      const int k = kSubs == 1 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
+      if (k >= nslots) continue;
       const QContact cn = slots.load(k);
       float jx[4];
       con_jx(cn, tw, jx);
@@ -885,23 +895,38 @@ struct QSolver {
         csum += ja < 0.f ? s.lim_D[k] * ja * ja : 0.f;
       }
     }
-    auto add_contact = [&](const QContact& cn, const float* ja4) {
+    auto add_contact = [](const QContact& cn, const float* ja4, S6& F, float& cs) {
       float f[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         float ja = ja4[r];
         f[r] = ja < 0.f ? -cn.D * ja : 0.f;
-        csum += ja < 0.f ? cn.D * ja * ja : 0.f;
+        cs += ja < 0.f ? cn.D * ja * ja : 0.f;
       }
       float g[3] = {f[0] + f[1] + f[2] + f[3], cn.mu * (f[0] - f[1]), cn.mu * (f[2] - f[3])};
       V3 fw = cn.fr[0] * g[0] + cn.fr[1] * g[1] + cn.fr[2] * g[2];
-      Fs.l = Fs.l + fw; Fs.a = Fs.a + cross(cn.off, fw);
+      F.l = F.l + fw; F.a = F.a + cross(cn.off, fw);
     };
-    if (any_con0) add_contact(s.con0, jar0);
-    for (int k = 0; k < nslots; k++) {
-      const QContact cn = slots.load(k);
-      float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
-      add_contact(cn, ja4);
+    if (any_con0) add_contact(s.con0, jar0, Fs, csum);
+    if (kSubs == 1) {
+      for (int k = 0; k < nslots; k++) {
+        const QContact cn = slots.load(k);
+        float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
+        add_contact(cn, ja4, Fs, csum);
+      }
+    } else if (nslots > 0) {
+      // hex layout: the owner of a slot forms its force; the sub-lane sum gives every lane the leg's total
+      S6 Fd{v3(0, 0, 0), v3(0, 0, 0)}; float cd = 0.f;
+      for (int k0 = 0; k0 < (kSubs == 1 ? nslots : (nslots > 0 ? 1 : 0)); k0++) {
+        const int k = kSubs == 1 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
+        if (k >= nslots) continue;
+        const QContact cn = slots.load(k);
+        float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
+        add_contact(cn, ja4, Fd, cd);
+      }
+      Fs.l = Fs.l + v3(sub_sum(Fd.l.x), sub_sum(Fd.l.y), sub_sum(Fd.l.z));
+      Fs.a = Fs.a + v3(sub_sum(Fd.a.x), sub_sum(Fd.a.y), sub_sum(Fd.a.z));
+      csum += sub_sum(cd);
     }
     pb[0] = Fs.l.x; pb[1] = Fs.l.y; pb[2] = Fs.l.z;
 #pragma unroll
@@ -933,7 +958,7 @@ struct QSolver {
     for (int i = 0; i < 6; i++) H.ll[i] = s.M.ll[i];
 #pragma unroll
     for (int k = 0; k < 3; k++) H.ll[tri(k, k)] += jar_lim[k] < 0.f ? s.lim_D[k] : 0.f;
-    auto add_hessian = [&](const QContact& cn, const float* ja4) {
+    auto add_hessian = [&](const QContact& cn, const float* ja4, float* Gt, float* lbt, float* llt) {
       float w[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) w[r] = ja4[r] < 0.f ? cn.D : 0.f;
@@ -954,20 +979,44 @@ struct QSolver {
 #pragma unroll
       for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = 0; j <= i; j++) Gbb[tri(i, j)] += dot(col[i], y[j]);
+        for (int j = 0; j <= i; j++) Gt[tri(i, j)] += dot(col[i], y[j]);
 #pragma unroll
       for (int i = 0; i < 3; i++) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) H.lb[i * 6 + k] += dot(col[6 + i], y[k]);
+        for (int k = 0; k < 6; k++) lbt[i * 6 + k] += dot(col[6 + i], y[k]);
 #pragma unroll
-        for (int j = 0; j <= i; j++) H.ll[tri(i, j)] += dot(col[6 + i], y[6 + j]);
+        for (int j = 0; j <= i; j++) llt[tri(i, j)] += dot(col[6 + i], y[6 + j]);
       }
     };
-    if (any_con0) add_hessian(s.con0, jar0);
-    for (int k = 0; k < nslots; k++) {
-      const QContact cn = slots.load(k);
-      float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
-      add_hessian(cn, ja4);
+    if (any_con0) add_hessian(s.con0, jar0, Gbb, H.lb, H.ll);
+    if (kSubs == 1) {
+      for (int k = 0; k < nslots; k++) {
+        const QContact cn = slots.load(k);
+        float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
+        add_hessian(cn, ja4, Gbb, H.lb, H.ll);
+      }
+    } else if (nslots > 0) {
+      // hex layout: the owner of a slot forms its 45 Hessian entries; the sub-lane sums give every lane the leg's total
+      float Gd[21], lbd[18], lld[6];
+#pragma unroll
+      for (int i = 0; i < 21; i++) Gd[i] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 18; i++) lbd[i] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; i++) lld[i] = 0.f;
+      for (int k0 = 0; k0 < (kSubs == 1 ? nslots : (nslots > 0 ? 1 : 0)); k0++) {
+        const int k = kSubs == 1 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
+        if (k >= nslots) continue;
+        const QContact cn = slots.load(k);
+        float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
+        add_hessian(cn, ja4, Gd, lbd, lld);
+      }
+#pragma unroll
+      for (int i = 0; i < 21; i++) Gbb[i] += sub_sum(Gd[i]);
+#pragma unroll
+      for (int i = 0; i < 18; i++) H.lb[i] += sub_sum(lbd[i]);
+#pragma unroll
+      for (int i = 0; i < 6; i++) H.ll[i] += sub_sum(lld[i]);
     }
 #pragma unroll
     for (int i = 0; i < 21; i++) H.bb[i] = s.M.bb[i] + quad_sum(Gbb[i]);
@@ -1094,7 +1143,9 @@ struct QSolver {
 #pragma unroll
       for (int r = 0; r < 4; r++) jv0[r] = s.con0.row_active ? jx[r] : 0.f;
     }
-    for (int k = 0; k < nslots; k++) {
+    for (int k0 = 0; k0 < (kSubs == 1 ? nslots : (nslots > 0 ? 1 : 0)); k0++) {
+      const int k = kSubs == 1 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
+      if (k >= nslots) continue;
       const QContact cn = slots.load(k);
       float jx[4];
       con_jx(cn, tws, jx);
@@ -1155,7 +1206,9 @@ struct QSolver {
     for (int k = 0; k < 3; k++) { ql[k] += sl[k] * ia; Mal[k] += mvl[k] * ia; jar_lim[k] += jv_lim[k] * ia; }
 #pragma unroll
     for (int r = 0; r < 4; r++) jar0[r] += jv0[r] * ia;
-    for (int k = 0; k < nslots; k++) {
+    for (int k0 = 0; k0 < (kSubs == 1 ? nslots : (nslots > 0 ? 1 : 0)); k0++) {
+      const int k = kSubs == 1 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
+      if (k >= nslots) continue;
 #pragma unroll
       for (int r = 0; r < 4; r++) slots.jar(k, r) += slots.jv(k, r) * ia;
     }
