@@ -814,6 +814,8 @@ struct QSolver {
   float jar_lim[3], jar0[4];
   float gauss, cost, prev_cost;
   int nslots;     // wave-uniform number of own-box-contact slots in use anywhere in the wave
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 hx_ja, hx_jv, hx_D;    // hex layout: (limit row, plane-contact row) of the own sub-lane for the current line search
   bool any_lim, any_con0;   // wave-uniform: some lane has an active joint-limit row / an active plane contact.
                             // Inactive rows have D = 0 and aref = 0: they add exact zeros, so skipping them is bit-neutral.
   const BoxSlots slots;
@@ -1041,7 +1043,6 @@ struct QSolver {
   // Two constraint rows at NA trial steps, in packed fp32 (v_pk_*: two rows per instruction).  The quadratic pieces
   // h = D * (ja^2/2, jv ja, jv^2/2) are formed once and added where the row is active (ja + alpha jv < 0); m * h with
   // m in {0, 1} is exact, so the sums are those of an un-fused evaluation (even and odd rows in separate chains).
-  typedef float f2 __attribute__((ext_vector_type(2)));
   template <int NA>
   PG_INL static void ls_row2(f2 ja, f2 jv, float D, const float* al, f2 (*q)[3]) {
     const f2 h0 = D * (0.5f * ja * ja), h1 = D * (jv * ja), h2 = D * (0.5f * jv * jv);
@@ -1082,12 +1083,7 @@ struct QSolver {
       // hex layout: sub-lane r evaluates row r of every constraint of its leg (limit row r < 3, pyramid row r of the
       // plane contact and of each box slot); the sums below run over all 16 lanes of the env
       const int r = threadIdx.x & 3;
-      if (any_lim || any_con0) {
-        const f2 ja{sel4(r, jar_lim[0], jar_lim[1], jar_lim[2], 0.f), sel4(r, jar0[0], jar0[1], jar0[2], jar0[3])};
-        const f2 jv{sel4(r, jv_lim[0], jv_lim[1], jv_lim[2], 0.f), sel4(r, jv0[0], jv0[1], jv0[2], jv0[3])};
-        const f2 D{sel4(r, s.lim_D[0], s.lim_D[1], s.lim_D[2], 0.f), s.con0.D};
-        ls_row2d<NA>(ja, jv, D, al, q);
-      }
+      if (any_lim || any_con0) ls_row2d<NA>(hx_ja, hx_jv, hx_D, al, q);       // own (limit row, plane row), picked once per search
       for (int k = 0; k < nslots; k += 2) {
         const bool two = k + 1 < nslots;
         const int k1 = two ? k + 1 : k;
@@ -1151,6 +1147,15 @@ struct QSolver {
       con_jx(cn, tws, jx);
 #pragma unroll
       for (int r = 0; r < 4; r++) slots.jv(k, r) = cn.row_active ? jx[r] : 0.f;
+    }
+    if (kSubs == 4) {
+      // pick by bit tests (selects, no branches): r = 0..3
+      const int r = threadIdx.x & 3;
+      const bool b0 = (r & 1) != 0, b1 = (r & 2) != 0;
+      auto pick = [&](float x0, float x1, float x2, float x3) { const float lo = b0 ? x1 : x0, hi = b0 ? x3 : x2; return b1 ? hi : lo; };
+      hx_ja = f2{pick(jar_lim[0], jar_lim[1], jar_lim[2], 0.f), pick(jar0[0], jar0[1], jar0[2], jar0[3])};
+      hx_jv = f2{pick(jv_lim[0], jv_lim[1], jv_lim[2], 0.f), pick(jv0[0], jv0[1], jv0[2], jv0[3])};
+      hx_D = f2{pick(s.lim_D[0], s.lim_D[1], s.lim_D[2], 0.f), s.con0.D};
     }
     float ab = 0.f, bb_ = 0.f, eb = 0.f, al = 0.f, bl = 0.f, el = 0.f;
 #pragma unroll
