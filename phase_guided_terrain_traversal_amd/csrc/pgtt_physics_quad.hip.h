@@ -753,7 +753,7 @@ struct QPhysics {
         for (int i = 0; i < kMaxPenQ; i++) {
           if (i >= ncol) continue;
 #pragma unroll
-          for (int j = 0; j < 4; j++) crank[j][i] += (key < ckey[j][i] || (key == ckey[j][i] && idx < cidx[j][i])) ? 1 : 0;
+          for (int j = 0; j < 4; j++) crank[j][i] += ((key < ckey[j][i]) | ((key == ckey[j][i]) & (idx < cidx[j][i]))) ? 1 : 0;   // `|`, `&`: no short-circuit branches
         }
       }
 #pragma unroll
@@ -770,7 +770,7 @@ struct QPhysics {
     for (int i = 0; i < kMaxPenQ; i++) {
       mine[i] = false;
 #pragma unroll
-      for (int j = 0; j < 4; j++) taken[j][i] = !(cdist[j][i] < 0.f) || (broad && need_exact && crank[j][i] >= maxp);
+      for (int j = 0; j < 4; j++) taken[j][i] = (!(cdist[j][i] < 0.f)) | ((broad & need_exact) & (crank[j][i] >= maxp));
     }
     const int nslot = (maxc > -1 && maxc < 4) ? maxc : 4;
     for (int k = 0; k < nslot; k++) {
@@ -779,14 +779,15 @@ struct QPhysics {
       for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int i = 0; i < kMaxPenQ; i++) {
-          bool better = !taken[j][i] && (bj < 0 || cdist[j][i] < bd || (cdist[j][i] == bd && crank[j][i] < br));
-          if (better) { bj = j; bi = i; bd = cdist[j][i]; br = crank[j][i]; }
+          // bitwise on purpose: sixteen short-circuit chains become sixteen branches otherwise
+          const bool better = (!taken[j][i]) & ((bj < 0) | (cdist[j][i] < bd) | ((cdist[j][i] == bd) & (crank[j][i] < br)));
+          bj = better ? j : bj; bi = better ? i : bi; bd = better ? cdist[j][i] : bd; br = better ? crank[j][i] : br;
         }
       if (__ballot(bj >= 0) == 0ull) break;
 #pragma unroll
       for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int i = 0; i < kMaxPenQ; i++) if (j == bj && i == bi) { taken[j][i] = true; if (j == l) mine[i] = true; }
+        for (int i = 0; i < kMaxPenQ; i++) { const bool hit = (j == bj) & (i == bi); taken[j][i] |= hit; mine[i] |= hit & (j == l); }
     }
     // own selected pairs: park (dist, box, point, normal) in the slot records
     int nb = 0;
