@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
       bool touching = s.con0.dist < 0.f;
       if (HAS_TERRAIN) {
 #pragma unroll
-        for (int k = 0; k < kMaxB; k++) touching = touching || (k < s.nbox && slots.at(k, 0) < 0.f);
+        for (int k = 0; k < kMaxB; k++) touching |= (k < s.nbox) & (slots.at(k, 0) < 0.f);
       }
       // box-contact slot numbering of the debug record: own contacts follow those of the lower legs
       const int n0 = quad_bcast<0>(s.nbox), n1 = quad_bcast<1>(s.nbox), n2 = quad_bcast<2>(s.nbox), n3 = quad_bcast<3>(s.nbox);

@@ -87,11 +87,13 @@ PG_INL bool owns_slot(int k) { return PG_SUBS == 1 || (int)(threadIdx.x & 3) == 
 template <int J> PG_INL float quad_bcast(float x) { return dpp_f<J * 0x55>(x); }
 template <int J> PG_INL int quad_bcast(int x) { return dpp_i<J * 0x55>(x); }
 #else
-// row_ror:4k hands lane i the value of lane i - 4k, i.e. of leg (own - k) & 3
+// row_ror:4k hands lane i the value of lane i - 4k, i.e. of leg (own - k) & 3; picked with two levels of selects
 template <int J> PG_INL int quad_bcast(int x) {
   const int k = ((int)(threadIdx.x >> 2) - J) & 3;
+  const bool b0 = (k & 1) != 0, b1 = (k & 2) != 0;
   const int r1 = dpp_i<0x124>(x), r2 = dpp_i<0x128>(x), r3 = dpp_i<0x12C>(x);
-  return k == 0 ? x : (k == 1 ? r1 : (k == 2 ? r2 : r3));
+  const int lo = b0 ? r1 : x, hi = b0 ? r3 : r2;
+  return b1 ? hi : lo;
 }
 template <int J> PG_INL float quad_bcast(float x) { return __int_as_float(quad_bcast<J>(__float_as_int(x))); }
 #endif
@@ -663,9 +665,10 @@ struct QPhysics {
     for (int i = 0; i < kMaxPenQ; i++) { pen[i].dist = 1.f; pen[i].key = 3.0e38f; pen[i].idx = 0x7fffffff; pen[i].pos = v3(0, 0, 0); pen[i].n = v3(0, 0, 1); }
     // lowest set bit of the 128-bit mask (-1 if empty), cleared
     auto pop = [&]() {
-      const bool have = (cm[0] | cm[1] | cm[2] | cm[3]) != 0u;
-      const int w = cm[0] ? 0 : (cm[1] ? 1 : (cm[2] ? 2 : 3));
-      const unsigned word = w == 0 ? cm[0] : (w == 1 ? cm[1] : (w == 2 ? cm[2] : cm[3]));
+      const bool z0 = cm[0] == 0u, z1 = z0 & (cm[1] == 0u), z2 = z1 & (cm[2] == 0u);
+      const bool have = !(z2 & (cm[3] == 0u));
+      const int w = (int)z0 + (int)z1 + (int)z2;                      // first non-empty word
+      const unsigned w23 = z2 ? cm[3] : cm[2], w12 = z1 ? w23 : cm[1], word = z0 ? w12 : cm[0];
       const int bit = have ? (__ffs(word) - 1) : 0;
       const unsigned clr = have ? ~(1u << bit) : ~0u;
       cm[0] &= w == 0 ? clr : ~0u; cm[1] &= w == 1 ? clr : ~0u; cm[2] &= w == 2 ? clr : ~0u; cm[3] &= w == 3 ? clr : ~0u;
