@@ -193,7 +193,8 @@ PG_INL void sphere_box(V3 c_world, float radius, const TerrainBox& tb, float& di
   }
   float au0 = 0, av0 = 0, bu0 = 0, bv0 = 0;
 #pragma unroll
-  for (int k = 0; k < 4; k++) if (k == idx) { int k0 = (k + 3) & 3; au0 = fu[k0]; av0 = fv[k0]; bu0 = fu[k]; bv0 = fv[k]; }
+  for (int k = 0; k < 4; k++) { const bool hit = k == idx; const int k0 = (k + 3) & 3;
+    au0 = hit ? fu[k0] : au0; av0 = hit ? fv[k0] : av0; bu0 = hit ? fu[k] : bu0; bv0 = hit ? fv[k] : bv0; }
   float abu = bu0 - au0, abv = bv0 - av0;
   float t = ((pu - au0) * abu + (pv - av0) * abv) / (abu * abu + abv * abv + 1e-6f);
   t = fminf(fmaxf(t, 0.f), 1.f);

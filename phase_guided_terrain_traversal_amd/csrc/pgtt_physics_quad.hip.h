@@ -691,7 +691,9 @@ struct QPhysics {
         // all four and keeps its own)
         const int r = threadIdx.x & 3;
         const int b0 = pop(), b1 = pop(), b2 = pop(), b3 = pop();
-        b = r == 0 ? b0 : (r == 1 ? b1 : (r == 2 ? b2 : b3));
+        const bool h0 = (r & 1) != 0, h1 = (r & 2) != 0;           // selects, not branches
+        const int lo = h0 ? b1 : b0, hi = h0 ? b3 : b2;
+        b = h1 ? hi : lo;
       }
       const bool have = b >= 0;
       TerrainBox tb = boxes[have ? b : 0];
