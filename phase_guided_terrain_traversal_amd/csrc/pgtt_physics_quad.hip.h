@@ -769,30 +769,36 @@ struct QPhysics {
       }
     }
     PG_TICK(s, 14);
-    // replicated selection of the max_contact_points deepest survivors (ties: lower broad-phase rank first)
-    bool taken[4][kMaxPenQ], mine[kMaxPenQ];
-#pragma unroll
-    for (int i = 0; i < kMaxPenQ; i++) {
-      mine[i] = false;
-#pragma unroll
-      for (int j = 0; j < 4; j++) taken[j][i] = (!(cdist[j][i] < 0.f)) | ((broad & need_exact) & (crank[j][i] >= maxp));
-    }
+    // selection of the max_contact_points deepest survivors of the env (ties: lower broad-phase rank first, then the
+    // scan order leg-major): MJX's sequential top-k picks exactly the pairs that fewer than max_contact_points others
+    // beat, so every lane only ranks its OWN pairs against the table — no selection rounds.
     const int nslot = (maxc > -1 && maxc < 4) ? maxc : 4;
-    for (int k = 0; k < nslot; k++) {
-      int bj = -1, bi = -1; float bd = 0.f; int br = 0;
+    bool mine[kMaxPenQ];
+    {
+      bool ok[4][kMaxPenQ];
 #pragma unroll
-      for (int j = 0; j < 4; j++)
+      for (int i = 0; i < kMaxPenQ; i++)
 #pragma unroll
-        for (int i = 0; i < kMaxPenQ; i++) {
-          // bitwise on purpose: sixteen short-circuit chains become sixteen branches otherwise
-          const bool better = (!taken[j][i]) & ((bj < 0) | (cdist[j][i] < bd) | ((cdist[j][i] == bd) & (crank[j][i] < br)));
-          bj = better ? j : bj; bi = better ? i : bi; bd = better ? cdist[j][i] : bd; br = better ? crank[j][i] : br;
-        }
-      if (__ballot(bj >= 0) == 0ull) break;
+        for (int j = 0; j < 4; j++) ok[j][i] = (cdist[j][i] < 0.f) & !((broad & need_exact) & (crank[j][i] >= maxp));
 #pragma unroll
-      for (int j = 0; j < 4; j++)
+      for (int i = 0; i < kMaxPenQ; i++) {
+        if (i >= ncol) { mine[i] = false; continue; }
+        // own pair (l, i): values through selects on the leg index
+        const float d = sel4(l, cdist[0][i], cdist[1][i], cdist[2][i], cdist[3][i]);
+        const int r = l == 0 ? crank[0][i] : (l == 1 ? crank[1][i] : (l == 2 ? crank[2][i] : crank[3][i]));
+        const bool okm = l == 0 ? ok[0][i] : (l == 1 ? ok[1][i] : (l == 2 ? ok[2][i] : ok[3][i]));
+        const int ord = l * kMaxPenQ + i;
+        int beat = 0;
 #pragma unroll
-        for (int i = 0; i < kMaxPenQ; i++) { const bool hit = (j == bj) & (i == bi); taken[j][i] |= hit; mine[i] |= hit & (j == l); }
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int i2 = 0; i2 < kMaxPenQ; i2++) {
+            if (i2 >= ncol) continue;
+            const bool first = (cdist[j][i2] < d) | ((cdist[j][i2] == d) & ((crank[j][i2] < r) | ((crank[j][i2] == r) & (j * kMaxPenQ + i2 < ord))));
+            beat += (ok[j][i2] & first) ? 1 : 0;
+          }
+        mine[i] = okm & (beat < nslot);
+      }
     }
     // own selected pairs: park (dist, box, point, normal) in the slot records
     int nb = 0;
