@@ -513,17 +513,22 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
   for (int io = lane; io < OBSD; io += 64) {
     // i = row in the PGTT layout; the baseline layout drops rows 30..37 (phase) and 38 + NSCAN (gait_freq)
     const int i = !baseline ? io : (io < 30 ? io : (io < 30 + PGTT_NSCAN ? io + 8 : io + 9));
-    float v;
-    if (i < 3) v = sh_fr[PGTT_F_GYRO + i] + (2.f * rng_uniform(a.seed, id, ep, PGTT_RS_GYRO, i) - 1.f) * lvl * cfg->noise_gyro;
-    else if (i < 6) v = sh_fr[PGTT_F_GRAVITY + i - 3] + (2.f * rng_uniform(a.seed, id, ep, PGTT_RS_GRAVITY, i - 3) - 1.f) * lvl * cfg->noise_gravity;
-    else if (i < 18) v = (sh_st[PGTT_S_QPOS + 7 + i - 6] + (2.f * rng_uniform(a.seed, id, ep, PGTT_RS_QPOS, i - 6) - 1.f) * lvl * cfg->noise_joint_pos) - m->key_qpos[7 + i - 6];
-    else if (i < 30) v = sh_st[PGTT_S_QVEL + 6 + i - 18] + (2.f * rng_uniform(a.seed, id, ep, PGTT_RS_QVEL, i - 18) - 1.f) * lvl * cfg->noise_joint_vel;
-    else if (i < 34) v = cosf(sel4(i - 30, phase[0], phase[1], phase[2], phase[3]));
-    else if (i < 38) v = sinf(sel4(i - 34, phase[0], phase[1], phase[2], phase[3]));
-    else if (i < 38 + PGTT_NSCAN) v = (sh_scan[i - 38] - zmin) + (2.f * rng_uniform(a.seed, id, ep, PGTT_RS_SCAN, i - 38) - 1.f) * lvl * cfg->noise_heightscan;
-    else if (i == 38 + PGTT_NSCAN) v = gait_freq;
-    else if (i < 39 + PGTT_NSCAN + 12) v = sh_st[PGTT_S_LAST_ACT + i - (39 + PGTT_NSCAN)];
-    else v = sel4(i - (51 + PGTT_NSCAN), cmd[0], cmd[1], cmd[2], 0.f);
+    // every row is (base + noise) - offset with noise = (2u - 1) * level * scale: the arms only pick the operands, the
+    // Philox draw is made ONCE per row (rows without noise draw too, with scale 0)
+    float base, scale = 0.f, offs = 0.f; int stream = PGTT_RS_GYRO, sidx = 0;
+    if (i < 3) { base = sh_fr[PGTT_F_GYRO + i]; stream = PGTT_RS_GYRO; sidx = i; scale = cfg->noise_gyro; }
+    else if (i < 6) { base = sh_fr[PGTT_F_GRAVITY + i - 3]; stream = PGTT_RS_GRAVITY; sidx = i - 3; scale = cfg->noise_gravity; }
+    else if (i < 18) { base = sh_st[PGTT_S_QPOS + 7 + i - 6]; stream = PGTT_RS_QPOS; sidx = i - 6; scale = cfg->noise_joint_pos; offs = m->key_qpos[7 + i - 6]; }
+    else if (i < 30) { base = sh_st[PGTT_S_QVEL + 6 + i - 18]; stream = PGTT_RS_QVEL; sidx = i - 18; scale = cfg->noise_joint_vel; }
+    else if (i < 34) base = cosf(sel4(i - 30, phase[0], phase[1], phase[2], phase[3]));
+    else if (i < 38) base = sinf(sel4(i - 34, phase[0], phase[1], phase[2], phase[3]));
+    else if (i < 38 + PGTT_NSCAN) { base = sh_scan[i - 38] - zmin; stream = PGTT_RS_SCAN; sidx = i - 38; scale = cfg->noise_heightscan; }
+    else if (i == 38 + PGTT_NSCAN) base = gait_freq;
+    else if (i < 39 + PGTT_NSCAN + 12) base = sh_st[PGTT_S_LAST_ACT + i - (39 + PGTT_NSCAN)];
+    else base = sel4(i - (51 + PGTT_NSCAN), cmd[0], cmd[1], cmd[2], 0.f);
+    const float u = rng_uniform(a.seed, id, ep, (unsigned)stream, sidx);
+    const float noisy = scale != 0.f ? base + (2.f * u - 1.f) * lvl * scale : base;
+    const float v = offs != 0.f ? noisy - offs : noisy;
     sh_obs[io] = v;
   }
   if (lane < PGTT_PRIV - PGTT_OBS) {
