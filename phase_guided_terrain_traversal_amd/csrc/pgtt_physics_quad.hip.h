@@ -220,18 +220,59 @@ PG_INL void qarrow_factor(QArrow& A) {
   float l22 = sqrtf(c[5] - l20 * l20 - l21 * l21);
   c[0] = l00; c[1] = l10; c[2] = l11; c[3] = l20; c[4] = l21; c[5] = l22;
   float* w = A.lb;
+  if (kSubs == 1) {
 #pragma unroll
-  for (int k = 0; k < 6; k++) {
-    float w0 = w[k] / l00;
-    float w1 = (w[6 + k] - l10 * w0) / l11;
-    float w2 = (w[12 + k] - l20 * w0 - l21 * w1) / l22;
-    w[k] = w0; w[6 + k] = w1; w[12 + k] = w2;
+    for (int k = 0; k < 6; k++) {
+      float w0 = w[k] / l00;
+      float w1 = (w[6 + k] - l10 * w0) / l11;
+      float w2 = (w[12 + k] - l20 * w0 - l21 * w1) / l22;
+      w[k] = w0; w[6 + k] = w1; w[12 + k] = w2;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++)
+        A.bb[tri(i, j)] -= quad_sum(w[i] * w[j] + w[6 + i] * w[6 + j] + w[12 + i] * w[12 + j]);
+  } else {
+    // hex layout: the leg blocks are replicated over the four sub-lanes, so the six columns of W = L^-1 A_lb (three
+    // divisions each) and the 21 Schur sums go round the sub-lanes and are handed back with sub-lane broadcasts; every
+    // lane ends with the same bits as if it had computed them all.
+    const int r = threadIdx.x & 3;
+    const bool b0 = (r & 1) != 0, b1 = (r & 2) != 0;
+    auto pick = [&](float x0, float x1, float x2, float x3) { const float lo = b0 ? x1 : x0, hi = b0 ? x3 : x2; return b1 ? hi : lo; };
+    // column r (all sub-lanes) and column 4 + r (sub-lanes 0, 1; the others redo column r + 2, unused)
+    float ca[3], cb[3];
+    {
+      const float a0 = pick(w[0], w[1], w[2], w[3]), a1 = pick(w[6], w[7], w[8], w[9]), a2 = pick(w[12], w[13], w[14], w[15]);
+      ca[0] = a0 / l00; ca[1] = (a1 - l10 * ca[0]) / l11; ca[2] = (a2 - l20 * ca[0] - l21 * ca[1]) / l22;
+      const float e0 = b0 ? w[5] : w[4], e1 = b0 ? w[11] : w[10], e2 = b0 ? w[17] : w[16];
+      cb[0] = e0 / l00; cb[1] = (e1 - l10 * cb[0]) / l11; cb[2] = (e2 - l20 * cb[0] - l21 * cb[1]) / l22;
+    }
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+      w[6 * m + 0] = sub_bcast<0>(ca[m]); w[6 * m + 1] = sub_bcast<1>(ca[m]); w[6 * m + 2] = sub_bcast<2>(ca[m]); w[6 * m + 3] = sub_bcast<3>(ca[m]);
+      w[6 * m + 4] = sub_bcast<0>(cb[m]); w[6 * m + 5] = sub_bcast<1>(cb[m]);
+    }
+    // Schur sums: entry t of the packed 6x6 triangle belongs to sub-lane t & 3
+    float mine[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) mine[q] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) {
+        const int t = tri(i, j);
+        const float p = w[i] * w[j] + w[6 + i] * w[6 + j] + w[12 + i] * w[12 + j];
+        mine[t >> 2] = (t & 3) == r ? p : mine[t >> 2];
+      }
+#pragma unroll
+    for (int q = 0; q < 6; q++) mine[q] = quad_sum(mine[q]);
+#pragma unroll
+    for (int t = 0; t < 21; t++) {
+      const float sm = (t & 3) == 0 ? sub_bcast<0>(mine[t >> 2]) : ((t & 3) == 1 ? sub_bcast<1>(mine[t >> 2]) : ((t & 3) == 2 ? sub_bcast<2>(mine[t >> 2]) : sub_bcast<3>(mine[t >> 2])));
+      A.bb[t] -= sm;
+    }
   }
-#pragma unroll
-  for (int i = 0; i < 6; i++)
-#pragma unroll
-    for (int j = 0; j <= i; j++)
-      A.bb[tri(i, j)] -= quad_sum(w[i] * w[j] + w[6 + i] * w[6 + j] + w[12 + i] * w[12 + j]);
 #pragma unroll
   for (int j = 0; j < 6; j++) {
     float s = A.bb[tri(j, j)];
