@@ -325,8 +325,8 @@ PG_INL float ray_box_down(const TerrainBox& tb, V3 p) {
     float side = f < 3 ? sz[ax] : -sz[ax];
     float x = (side - lp[ax]) / lv[ax];
     float p0 = lp[i0] + x * lv[i0], p1 = lp[i1] + x * lv[i1];
-    bool valid = (fabsf(p0) <= sz[i0]) && (fabsf(p1) <= sz[i1]) && (x >= 0.f);
-    best = (valid && x < best) ? x : best;
+    const bool valid = (fabsf(p0) <= sz[i0]) & (fabsf(p1) <= sz[i1]) & (x >= 0.f);     // `&`: selects, not branches
+    best = (valid & (x < best)) ? x : best;
   }
   return best;
 }
