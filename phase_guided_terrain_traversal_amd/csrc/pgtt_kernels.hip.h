@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
 #ifdef PGTT_TIME
   // stage ticks of the wave that owns env PGTT_TIME (e.g. -DPGTT_TIME=0): 0 position 1 velocity 2 constraint 3 sensors
   // 4 solver init x3 5 first gradient 6 line search 7 update_constraint 8 update_gradient 9 rest 10 #iterations
-  if (e == PGTT_TIME && a.trace) for (int i = 0; i < 18; i++) a.trace[i] = s.cyc[i];
+  if (e == PGTT_TIME && a.trace) for (int i = 0; i < 20; i++) a.trace[i] = s.cyc[i];
   if (a.trace) {      // per-wave totals: [32 + block] ticks of the whole kernel, [32 + 4096 + block] sum over substeps of nslots
     float tot = 0.f;
     for (int i = 0; i < 10; i++) tot += i == 9 ? 0.f : s.cyc[i];

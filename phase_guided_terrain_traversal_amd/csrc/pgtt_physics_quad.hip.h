@@ -177,7 +177,7 @@ struct QSim {
 #endif
 #ifdef PGTT_TIME
   // stage timer (-DPGTT_TIME builds): cyc[i] accumulates shader-clock ticks of stage i over the launch
-  long long tlast = 0; float cyc[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = 0; float cyc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   PG_INL void tick(int stage) { long long t = __builtin_readcyclecounter(); cyc[stage] += (float)(t - tlast); tlast = t; }
 #define PG_TICK(sim, stage) (sim).tick(stage)
   PG_INL void cyc_iter() { cyc[10] += 1.f; }
@@ -1244,6 +1244,10 @@ struct QSolver {
     for (;;) {
       bool done = it >= m->ls_iterations || !swap || ((lo.d0 < 0.f) && (lo.d0 > -gtol)) || ((hi.d0 > 0.f) && (hi.d0 < gtol));
       if (__ballot(!done) == 0ull) break;
+#ifdef PGTT_TIME
+      s.cyc[18] += 1.f;           // line-search rounds executed by this wave
+      s.cyc[19] += done ? 0.f : 1.f;   // ... of which this env needed
+#endif
       const float al3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha)};
       LSPoint pt[3];
       ls_points<3>(al3, jv_lim, jv0, qg0, qg1, qg2, pt);
