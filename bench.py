@@ -90,6 +90,9 @@ def main():
 
     run(0, args.warmup)
     torch.cuda.synchronize()
+    # per-kernel durations over the timed steps themselves: HIP events recorded by libpgtt around its own launches on
+    # the launch stream (every 8th step), kept in a ring and read back later (no stall in the timed loop)
+    env.enable_timing(8)          # every 8th step: an event record costs a few us of GPU idle
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -104,16 +107,8 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-
-    # per-kernel durations: HIP events recorded by libpgtt around its own launches on the launch stream
-    env.enable_timing(True)
-    phys, obsv = [], []
-    for k in range(30):
-        env.step(pool[k % len(pool)])
-        p, o = env.last_kernel_ms()
-        phys.append(p); obsv.append(o)
+    phys_ms, obs_ms, ntimed = env.kernel_ms_mean()
     env.enable_timing(False)
-    phys_ms, obs_ms = float(np.mean(phys)), float(np.mean(obsv))
     done_frac = float(env.buffers["done"].mean().item())
 
     if rank == 0:
@@ -138,7 +133,7 @@ def main():
                                     "level13_dr": "Go2 envs/GPU, level13 + full randomize.py DR (BASELINE configs[3] shape)",
                                     "wfc_dr": "Go2 envs/GPU, WFC-generated stairs (terrain_gen.py, 100 variants) + full randomize.py DR (BASELINE configs[3])"}[args.workload],
                        "envs_per_gpu": n, "substeps": 4, "autoreset": True, "actions": "tanh(N(0,0.6)) iid", "parallelism": f"env-shard x{world}"},
-            "kernels_ms": {"physics_kernel": phys_ms, "observe_kernel": obs_ms},
+            "kernels_ms": {"physics_kernel": phys_ms, "observe_kernel": obs_ms, "launches": ntimed},
             "done_fraction_last_step": done_frac,
             "roofline": {"bound": "mfma", "achieved": algo_flop / (phys_ms * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": algo_flop / (phys_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, "traffic": traffic,

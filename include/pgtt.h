@@ -254,10 +254,14 @@ int pgtt_physics(pgtt_handle h, const float* action_Nx12, void* stream);  /* 4 x
 int pgtt_observe(pgtt_handle h, const float* action_Nx12, void* stream);  /* scan + obs + rewards + bookkeeping */
 int pgtt_scan(pgtt_handle h, float yaw_override_or_nan, void* stream);     /* K11 alone -> scan_z */
 
-/* time of the most recent physics / observe kernels, measured with HIP events on `stream`
+/* enable = 0 off, 1 time every step, n > 1 time every n-th step (an event record costs a few us of GPU idle).
+ * time of the most recent physics / observe kernels, measured with HIP events on `stream`
  * (valid after the stream is synchronised; used by bench.py for the roofline figure). */
 int pgtt_enable_timing(pgtt_handle h, int enable);
 int pgtt_last_kernel_ms(pgtt_handle h, float* physics_ms, float* observe_ms);
+/* mean kernel times over ALL steps since pgtt_enable_timing(h, 1): events are kept in a ring and read back when their
+ * slot is re-used, so timing a long run does not stall the stream; synchronises on the steps still in flight */
+int pgtt_kernel_ms_mean(pgtt_handle h, float* physics_ms, float* observe_ms, int* steps);
 
 /* observation widths for cfg->method (env.observation_size of the reference, go2/joystick*.py) */
 int pgtt_obs_dims(const PgttConfig* cfg, int* state_dim, int* priv_dim);

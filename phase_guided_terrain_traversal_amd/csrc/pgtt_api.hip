@@ -47,8 +47,15 @@ struct pgtt_env {
   unsigned long long seed = 0;
   long long env_off = 0;
   bool timing = false;
+  int timing_period = 1, timing_tick = 0; bool timing_now = false;   // time every timing_period-th step (event records cost ~3 us of GPU idle each)
   int layout = 0;                 // lane layout of physics_kernel: 1 quad (16 envs per wave), 4 hex (4 envs per wave), 0 auto
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // kernel timing: a ring of event quadruples (physics begin / end, observe begin / end), one per step; a slot is
+  // read back when it comes up for re-use (its step finished long ago: no stall) or by pgtt_kernel_ms_mean()
+  static constexpr int kRing = 64;
+  hipEvent_t ev[kRing][4] = {};
+  bool ev_used[kRing] = {};
+  int ev_slot = -1;               // slot of the most recent step
+  double sum_phys = 0.0, sum_obs = 0.0; long n_timed = 0;
   bool ev_valid = false;
 };
 
@@ -76,6 +83,17 @@ pgtt::KArgs make_args(pgtt_env* h, const unsigned char* mask, float yaw_override
   a.trace = pgtt_trace_buffer();
 #endif
   return a;
+}
+
+// add the kernel times of ring slot r (if it holds a finished or pending step) to the running sums and free the slot
+int harvest(pgtt_env* h, int r) {
+  if (!h->ev_used[r]) return PGTT_OK;
+  float p = 0.f, o = 0.f;
+  HIP_TRY(hipEventSynchronize(h->ev[r][3]));
+  HIP_TRY(hipEventElapsedTime(&p, h->ev[r][0], h->ev[r][1]));
+  HIP_TRY(hipEventElapsedTime(&o, h->ev[r][2], h->ev[r][3]));
+  h->sum_phys += p; h->sum_obs += o; h->n_timed++; h->ev_used[r] = false;
+  return PGTT_OK;
 }
 
 template <int MODE>
@@ -157,7 +175,7 @@ int pgtt_create(const PgttConfig* cfg, const PgttModel* model, int device, int n
   HIP_TRY(hipMalloc(&h->d_model, sizeof(PgttModel)));
   HIP_TRY(hipMemcpy(h->d_cfg, cfg, sizeof(PgttConfig), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->d_model, model, sizeof(PgttModel), hipMemcpyHostToDevice));
-  for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&h->ev[i]));
+  for (int r = 0; r < pgtt_env::kRing; r++) for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&h->ev[r][i]));
   *out = h;
   return PGTT_OK;
 }
@@ -168,7 +186,7 @@ int pgtt_destroy(pgtt_handle h) {
   if (h->d_cfg) hipFree(h->d_cfg);
   if (h->d_model) hipFree(h->d_model);
   if (h->d_terrain) hipFree(h->d_terrain);
-  for (int i = 0; i < 4; i++) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+  for (int r = 0; r < pgtt_env::kRing; r++) for (int i = 0; i < 4; i++) if (h->ev[r][i]) hipEventDestroy(h->ev[r][i]);
   delete h;
   return PGTT_OK;
 }
@@ -246,9 +264,14 @@ int pgtt_physics(pgtt_handle h, const float* action, void* stream) {
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   pgtt::KArgs a = make_args(h, nullptr, 0.f);
-  if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], st));
+  h->timing_now = h->timing && (h->timing_tick++ % h->timing_period) == 0;
+  if (h->timing_now) {
+    h->ev_slot = (h->ev_slot + 1) % pgtt_env::kRing;
+    if (int rc = harvest(h, h->ev_slot)) return rc;
+    HIP_TRY(hipEventRecord(h->ev[h->ev_slot][0], st));
+  }
   launch_physics<pgtt::MODE_STEP>(h, a, action, st);
-  if (h->timing) HIP_TRY(hipEventRecord(h->ev[1], st));
+  if (h->timing_now) HIP_TRY(hipEventRecord(h->ev[h->ev_slot][1], st));
   HIP_TRY(hipGetLastError());
   return PGTT_OK;
 }
@@ -259,9 +282,10 @@ int pgtt_observe(pgtt_handle h, const float* action, void* stream) {
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   pgtt::KArgs a = make_args(h, nullptr, 0.f);
-  if (h->timing) HIP_TRY(hipEventRecord(h->ev[2], st));
+  const bool timed = h->timing_now && h->ev_slot >= 0;
+  if (timed) HIP_TRY(hipEventRecord(h->ev[h->ev_slot][2], st));
   launch_observe<pgtt::OBS_STEP>(h, a, action, st);
-  if (h->timing) { HIP_TRY(hipEventRecord(h->ev[3], st)); h->ev_valid = true; }
+  if (timed) { HIP_TRY(hipEventRecord(h->ev[h->ev_slot][3], st)); h->ev_used[h->ev_slot] = true; h->ev_valid = true; }
   HIP_TRY(hipGetLastError());
   return PGTT_OK;
 }
@@ -282,16 +306,29 @@ int pgtt_scan(pgtt_handle h, float yaw_override_or_nan, void* stream) {
 
 int pgtt_enable_timing(pgtt_handle h, int enable) {
   if (!h) return fail(PGTT_E_ARG, "null handle");
-  h->timing = enable != 0; h->ev_valid = false;
+  h->timing = enable != 0; h->ev_valid = false; h->ev_slot = -1;
+  h->timing_period = enable > 1 ? enable : 1; h->timing_tick = 0; h->timing_now = false;
+  for (int r = 0; r < pgtt_env::kRing; r++) h->ev_used[r] = false;
+  h->sum_phys = 0.0; h->sum_obs = 0.0; h->n_timed = 0;
   return PGTT_OK;
 }
 
 int pgtt_last_kernel_ms(pgtt_handle h, float* physics_ms, float* observe_ms) {
   if (!h || !physics_ms || !observe_ms) return fail(PGTT_E_ARG, "pgtt_last_kernel_ms: null argument");
-  if (!h->timing || !h->ev_valid) return fail(PGTT_E_STATE, "pgtt_last_kernel_ms: timing not enabled or no step recorded");
-  HIP_TRY(hipEventSynchronize(h->ev[3]));
-  HIP_TRY(hipEventElapsedTime(physics_ms, h->ev[0], h->ev[1]));
-  HIP_TRY(hipEventElapsedTime(observe_ms, h->ev[2], h->ev[3]));
+  if (!h->timing || !h->ev_valid || h->ev_slot < 0 || !h->ev_used[h->ev_slot]) return fail(PGTT_E_STATE, "pgtt_last_kernel_ms: timing not enabled or no step recorded");
+  hipEvent_t* e = h->ev[h->ev_slot];
+  HIP_TRY(hipEventSynchronize(e[3]));
+  HIP_TRY(hipEventElapsedTime(physics_ms, e[0], e[1]));
+  HIP_TRY(hipEventElapsedTime(observe_ms, e[2], e[3]));
+  return PGTT_OK;
+}
+
+int pgtt_kernel_ms_mean(pgtt_handle h, float* physics_ms, float* observe_ms, int* steps) {
+  if (!h || !physics_ms || !observe_ms || !steps) return fail(PGTT_E_ARG, "pgtt_kernel_ms_mean: null argument");
+  if (!h->timing) return fail(PGTT_E_STATE, "pgtt_kernel_ms_mean: timing not enabled");
+  for (int r = 0; r < pgtt_env::kRing; r++) if (int rc = harvest(h, r)) return rc;
+  if (h->n_timed == 0) return fail(PGTT_E_STATE, "pgtt_kernel_ms_mean: no step recorded");
+  *physics_ms = (float)(h->sum_phys / h->n_timed); *observe_ms = (float)(h->sum_obs / h->n_timed); *steps = (int)h->n_timed;
   return PGTT_OK;
 }
 

@@ -143,13 +143,20 @@ class Joystick:
         native.check(self._lib.pgtt_scan(self._h, float("nan") if yaw is None else float(yaw), self._stream()))
         return self.buffers["scan_z"]
 
-    def enable_timing(self, on: bool = True) -> None:
+    def enable_timing(self, on=True) -> None:
+        """False / True / n > 1 = time every n-th step (HIP events around the kernels, on the launch stream)"""
         native.check(self._lib.pgtt_enable_timing(self._h, int(on)))
 
     def last_kernel_ms(self):
         p, o = C.c_float(), C.c_float()
         native.check(self._lib.pgtt_last_kernel_ms(self._h, C.byref(p), C.byref(o)))
         return p.value, o.value
+
+    def kernel_ms_mean(self):
+        """(physics ms, observe ms, steps): mean kernel times over all steps since enable_timing(True)"""
+        p, o, k = C.c_float(), C.c_float(), C.c_int()
+        native.check(self._lib.pgtt_kernel_ms_mean(self._h, C.byref(p), C.byref(o), C.byref(k)))
+        return p.value, o.value, k.value
 
     def close(self) -> None:
         if getattr(self, "_h", None):
