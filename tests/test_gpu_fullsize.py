@@ -158,3 +158,25 @@ def test_rollout_stays_finite_and_bounded():
     q = env.buffers["state"][3:7]
     assert torch.allclose((q * q).sum(0), torch.ones(N, device="cuda"), atol=1e-5)
     env.close()
+
+
+def test_kernel_timing_api():
+    """pgtt_enable_timing / pgtt_last_kernel_ms / pgtt_kernel_ms_mean: ring of HIP events, every n-th step"""
+    env, _, _ = make(n=512)
+    env.reset(seed=3)
+    env.enable_timing(True)
+    for k in range(70):                      # more steps than ring slots (64): slots are harvested on re-use
+        env.step(actions(k, 512))
+    p, o = env.last_kernel_ms()
+    pm, om, cnt = env.kernel_ms_mean()
+    assert cnt == 70 and 0.0 < pm < 50.0 and 0.0 < om < 50.0 and 0.0 < p < 50.0 and 0.0 < o < 50.0
+    env.enable_timing(8)
+    for k in range(33):
+        env.step(actions(k, 512))
+    pm, om, cnt = env.kernel_ms_mean()
+    assert cnt == 5 and pm > 0.0                # steps 0, 8, 16, 24, 32
+    env.enable_timing(False)
+    env.step(actions(0, 512))
+    with pytest.raises(Exception):
+        env.kernel_ms_mean()
+    env.close()
