@@ -354,7 +354,7 @@ PG_INL void qload_env_model(const PgttModel* __restrict__ m, const float* __rest
   }
 }
 
-struct QPen { float dist, key; int idx; V3 pos, n; };
+struct QPen { float dist, key; int idx; };     // a penetrating (foot, box) pair; its contact point and normal wait in LDS
 
 struct QPhysics {
   const PgttModel* __restrict__ m;
@@ -703,7 +703,8 @@ struct QPhysics {
     // pass 1b: narrow phase on the candidates in box order (every lane pops its own lowest set bit); penetrating pairs kept
     QPen pen[kMaxPenQ]; int npen = 0;
 #pragma unroll
-    for (int i = 0; i < kMaxPenQ; i++) { pen[i].dist = 1.f; pen[i].key = 3.0e38f; pen[i].idx = 0x7fffffff; pen[i].pos = v3(0, 0, 0); pen[i].n = v3(0, 0, 1); }
+    for (int i = 0; i < kMaxPenQ; i++) { pen[i].dist = 1.f; pen[i].key = 3.0e38f; pen[i].idx = 0x7fffffff; }
+    static_assert(kMaxPenQ <= kMaxB, "pair i parks its point / normal in the record of slot i");
     // lowest set bit of the 128-bit mask (-1 if empty), cleared
     auto pop = [&]() {
       const bool z0 = cm[0] == 0u, z1 = z0 & (cm[1] == 0u), z2 = z1 & (cm[2] == 0u);
@@ -715,22 +716,27 @@ struct QPhysics {
       cm[0] &= w == 0 ? clr : ~0u; cm[1] &= w == 1 ? clr : ~0u; cm[2] &= w == 2 ? clr : ~0u; cm[3] &= w == 3 ? clr : ~0u;
       return have ? w * 32 + bit : -1;
     };
+    // a penetrating pair takes the next free entry; (dist, key, idx) stay in registers for the selection, the contact
+    // point and normal wait in fields 7..12 of the slot record with the same index (dynamic LDS index instead of selects)
     auto keep = [&](const QPen& pp) {
-      if (pp.dist < 0.f && npen < kMaxPenQ) {
+      const bool take = (pp.dist < 0.f) & (npen < kMaxPenQ);
 #pragma unroll
-        for (int i = 0; i < kMaxPenQ; i++) if (i == npen) pen[i] = pp;
-        npen++;
-      }
+      for (int i = 0; i < kMaxPenQ; i++) { const bool hit = take & (i == npen); pen[i].dist = hit ? pp.dist : pen[i].dist; pen[i].key = hit ? pp.key : pen[i].key; pen[i].idx = hit ? pp.idx : pen[i].idx; }
+      npen += take ? 1 : 0;
+    };
+    auto park = [&](int at, V3 pw, V3 nw) {
+      slots.at(at, 7) = pw.x; slots.at(at, 8) = pw.y; slots.at(at, 9) = pw.z;
+      slots.at(at, 10) = nw.x; slots.at(at, 11) = nw.y; slots.at(at, 12) = nw.z;
     };
     for (;;) {
       if (__ballot((cm[0] | cm[1] | cm[2] | cm[3]) != 0u) == 0ull) break;
       int b;
+      const int r = threadIdx.x & 3;
       if (kSubs == 1) {
         b = pop();
       } else {
         // hex layout: the next four candidates go to the four sub-lanes (the mask is replicated, so every sub-lane pops
         // all four and keeps its own)
-        const int r = threadIdx.x & 3;
         const int b0 = pop(), b1 = pop(), b2 = pop(), b3 = pop();
         const bool h0 = (r & 1) != 0, h1 = (r & 2) != 0;           // selects, not branches
         const int lo = h0 ? b1 : b0, hi = h0 ? b3 : b2;
@@ -740,16 +746,20 @@ struct QPhysics {
       TerrainBox tb = boxes[have ? b : 0];
       float nd; V3 pw, nw;
       sphere_box(s.footc, rad, tb, nd, pw, nw);
-      QPen pp; pp.dist = have ? nd : 1.f; pp.key = norm(v3(tb.px, tb.py, tb.pz) - s.footc) - keyC; pp.idx = l * nbox + (have ? b : 0); pp.pos = pw; pp.n = nw;
+      QPen pp; pp.dist = have ? nd : 1.f; pp.key = norm(v3(tb.px, tb.py, tb.pz) - s.footc) - keyC; pp.idx = l * nbox + (have ? b : 0);
       if (kSubs == 1) {
+        if ((pp.dist < 0.f) & (npen < kMaxPenQ)) park(npen, pw, nw);
         keep(pp);
       } else {
-        // every lane appends the four results in candidate (= box index) order, as the sequential loop would
-#define PG_TAKE(Q) { QPen g; g.dist = sub_bcast<Q>(pp.dist); g.key = sub_bcast<Q>(pp.key); g.idx = sub_bcast<Q>(pp.idx); \
-                     g.pos = v3(sub_bcast<Q>(pp.pos.x), sub_bcast<Q>(pp.pos.y), sub_bcast<Q>(pp.pos.z));               \
-                     g.n = v3(sub_bcast<Q>(pp.n.x), sub_bcast<Q>(pp.n.y), sub_bcast<Q>(pp.n.z)); keep(g); }
-        PG_TAKE(0) PG_TAKE(1) PG_TAKE(2) PG_TAKE(3)
-#undef PG_TAKE
+        // every lane appends the four results in candidate (= box index) order, as the sequential loop would; the
+        // sub-lane that computed a penetrating pair parks its point / normal at the entry the pair is going to take
+        QPen g0{sub_bcast<0>(pp.dist), sub_bcast<0>(pp.key), sub_bcast<0>(pp.idx)}, g1{sub_bcast<1>(pp.dist), sub_bcast<1>(pp.key), sub_bcast<1>(pp.idx)};
+        QPen g2{sub_bcast<2>(pp.dist), sub_bcast<2>(pp.key), sub_bcast<2>(pp.idx)}, g3{sub_bcast<3>(pp.dist), sub_bcast<3>(pp.key), sub_bcast<3>(pp.idx)};
+        const int f0 = g0.dist < 0.f ? 1 : 0, f1 = g1.dist < 0.f ? 1 : 0, f2 = g2.dist < 0.f ? 1 : 0;
+        const bool h0 = (r & 1) != 0, h1 = (r & 2) != 0;
+        const int before = h1 ? (h0 ? f0 + f1 + f2 : f0 + f1) : (h0 ? f0 : 0);        // penetrating pairs of the lower sub-lanes
+        if ((pp.dist < 0.f) & (npen + before < kMaxPenQ)) park(npen + before, pw, nw);
+        keep(g0); keep(g1); keep(g2); keep(g3);
       }
     }
     PG_TICK(s, 13);
@@ -849,8 +859,9 @@ struct QPhysics {
       if (mine[i]) {
         slots.at(nb, 0) = pen[i].dist;
         slots.at(nb, 20) = __int_as_float(pen[i].idx - l * nbox);
-        slots.at(nb, 7) = pen[i].pos.x; slots.at(nb, 8) = pen[i].pos.y; slots.at(nb, 9) = pen[i].pos.z;
-        slots.at(nb, 10) = pen[i].n.x; slots.at(nb, 11) = pen[i].n.y; slots.at(nb, 12) = pen[i].n.z;
+        // point / normal move down from entry i to slot nb <= i (entries below i were consumed already)
+#pragma unroll
+        for (int f = 7; f <= 12; f++) { const float v = slots.at(i, f); slots.at(nb, f) = v; }
         nb++;
       }
     }
