@@ -1,7 +1,7 @@
 // pgtt_kernels.hip.h — __global__ kernels of libpgtt.so (gfx950).
 //
-//   physics_kernel  : one env per QUAD of lanes (lane = leg; 16 envs per 64-thread block), DPP quad reductions,
-//                     no LDS / scratch.  MODE_STEP = mjx_env.step (n_substeps x
+//   physics_kernel  : one env per 4 or 16 lanes (lane = leg [x sub-lane]; 16 or 4 envs per 64-thread block, see
+//                     pgtt_physics_quad.hip.h), DPP reductions.  MODE_STEP = mjx_env.step (n_substeps x
 //                     {forward, Euler}) + sensor frame + contact flags; MODE_FORWARD = one mjx.forward
 //                     (reset path).  Reference: go2/joystick_pgtt.py:146-148, :72, :78.
 //   observe_kernel  : one env per WAVE.  13x9 height scan with the terrain variant's boxes read through

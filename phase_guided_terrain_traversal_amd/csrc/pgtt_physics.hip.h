@@ -1,6 +1,6 @@
 // pgtt_physics.hip.h — shared device helpers of the physics kernel (gfx950, wave64): small vector / quaternion /
 // spatial algebra, the constraint impedance law, the sphere-box narrow phase and the resident terrain table entry.
-// The simulator itself is in pgtt_physics_quad.hip.h (one environment per QUAD of lanes).
+// The simulator itself is in pgtt_physics_quad.hip.h (one environment per 4 or 16 lanes).
 //
 // SoA state in HBM (buffer[row][env] => lane-coalesced loads/stores), model constants read through a
 // wave-uniform pointer (scalar loads).  This is NOT the dense MJX formulation the oracle restates: it exploits

@@ -1,16 +1,16 @@
-// pgtt_physics_quad.hip.h — the physics of one environment spread over a QUAD of lanes (gfx950, wave64).
+// pgtt_physics_quad.hip.h — the physics of one environment spread over 4 or 16 lanes (gfx950, wave64).
 //
-// Layout: lane = 4*q + l, q = env within the wave (16 envs per wave), l = leg (FL,FR,RL,RR = body-tree order).
-// Lane l owns leg l: its 3 links, 3 dofs, 3 joint-limit rows, its foot's plane contact and its foot's box
-// contacts, the leg blocks M_ll (3x3) / M_lb (3x6) of the arrowhead inertia and of the Newton Hessian.
-// Everything that belongs to the floating base (pose, COM, 6x6 base block, base parts of every 18-vector) is
-// REPLICATED in the four lanes and kept bitwise identical: cross-lane sums use a symmetric two-step DPP
-// butterfly (quad_perm [1,0,3,2] then [2,3,0,1]), which returns the same bits in all four lanes.
-// No LDS, no scratch: the per-lane working set (~300 floats) lives in VGPRs, and a 4096-env batch becomes
-// 256 waves (one per CU) instead of 64.
+// Lane l of an env owns LEG l (FL,FR,RL,RR = body-tree order): its 3 links, 3 dofs, 3 joint-limit rows, its foot's plane
+// contact and box contacts, the leg blocks M_ll (3x3) / M_lb (3x6) of the arrowhead inertia and of the Newton Hessian.
+// Everything that belongs to the floating base (pose, COM, 6x6 base block, base parts of every 18-vector) is REPLICATED
+// in the lanes of the env and kept bitwise identical: cross-lane sums are symmetric DPP butterflies that return the same
+// bits in every lane.  Two layouts (compile-time PG_SUBS, see "cross-lane primitives" below): quad = one lane per leg,
+// 16 envs per wave; hex = four sub-lanes per leg (leg state replicated, selected loops split), 4 envs per wave.
+// Box-contact records live in LDS (one column per leg); everything else is in registers (96-128 B of scratch in the
+// terrain kernels, none in the flat ones).
 //
-// Same arithmetic contract as the one-env-per-lane version (see pgtt_physics.hip.h header): MJX forward +
-// Euler for the Go2 tree, active contact set identical to MJX's top-k semantics, Newton(5) x linesearch(5).
+// Arithmetic contract: MJX forward + Euler for the Go2 tree, active contact set identical to MJX's top-k semantics,
+// Newton(5) x linesearch(5); see pgtt_physics.hip.h for the shared helpers and DESIGN.md 5.1 for the invariants.
 #pragma once
 #include "pgtt_physics.hip.h"
 
@@ -79,9 +79,8 @@ PG_INL unsigned sub_or(unsigned x) {
   return x;
 }
 // hex layout: sub-lane k of a leg OWNS box slot k of that leg: it alone completes the slot's record, forms its Jacobian
-// products and its force / Hessian contributions (summed over the sub-lanes afterwards), so that this work does not
-// grow with the number of slots in use; in the quad layout every lane owns all its slots.
-PG_INL bool owns_slot(int k) { return PG_SUBS == 1 || (int)(threadIdx.x & 3) == k; }
+// products and its force / Hessian contributions (summed over the sub-lanes afterwards), in ONE pass, so that this work
+// does not grow with the number of slots in use; in the quad layout every lane loops over all its slots.
 // value held by leg J (same sub-lane)
 #if PG_SUBS == 1
 template <int J> PG_INL float quad_bcast(float x) { return dpp_f<J * 0x55>(x); }
