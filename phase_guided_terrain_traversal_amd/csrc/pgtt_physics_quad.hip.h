@@ -568,20 +568,29 @@ struct QPhysics {
   // constraint rows: joint limits, the plane contact, and the box contacts found by collide() (world point / normal parked
   // in the slot record) completed with their Jacobian frame, impedance and reference acceleration
   PG_INL void constraint_stage(bool has_boxes, const float* __restrict__ box_fr, int N, int e, const BoxSlots& slots) {
+    float lpos[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       const int j = 3 * l + k;
       float q = s.ql[k];
       float dmin = q - m->jnt_range[j][0], dmax = m->jnt_range[j][1] - q;
-      float pos = fminf(dmin, dmax);
-      bool act = pos < 0.f;
-      s.lim_active[k] = act;
+      lpos[k] = fminf(dmin, dmax);
+      s.lim_active[k] = lpos[k] < 0.f;
       s.lim_sign[k] = dmin < dmax ? 1.0f : -1.0f;
-      float kimp, b, imp;
-      kbi(m->timestep, m->jnt_solref, m->jnt_solimp, pos, kimp, b, imp);
-      float r = fmaxf(m->dof_invweight0[6 + j] * (1.0f - imp) / imp, kMinVal);
-      s.lim_D[k] = act ? 1.0f / r : 0.f;
-      s.lim_aref[k] = act ? (-b * (s.lim_sign[k] * s.vl[k]) - kimp * pos) : 0.f;
+      s.lim_D[k] = 0.f; s.lim_aref[k] = 0.f;
+    }
+    // impedance of a limit row only matters when the row is active: skipped while no lane of the wave is past a limit
+    if (__ballot(s.lim_active[0] | s.lim_active[1] | s.lim_active[2]) != 0ull) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int j = 3 * l + k;
+        const bool act = s.lim_active[k];
+        float kimp, b, imp;
+        kbi(m->timestep, m->jnt_solref, m->jnt_solimp, lpos[k], kimp, b, imp);
+        float r = fmaxf(m->dof_invweight0[6 + j] * (1.0f - imp) / imp, kMinVal);
+        s.lim_D[k] = act ? 1.0f / r : 0.f;
+        s.lim_aref[k] = act ? (-b * (s.lim_sign[k] * s.vl[k]) - kimp * lpos[k]) : 0.f;
+      }
     }
     auto mix = [&](const float* sr1, const float* si1, float sm1, const float* sr2, const float* si2, float sm2, float* sr, float* si) {
       float mixw = sm1 / (sm1 + sm2);
@@ -602,7 +611,9 @@ struct QPhysics {
       c.dist = s.footc.z - rad;
       V3 pos = s.footc - v3(0, 0, 1) * (rad + 0.5f * c.dist);
       contact_jac(c, pos, v3(0, 0, 1), v3(0, 1, 0), v3(-1, 0, 0), 1.0f);
-      finish_contact(c, sr, si, margin, invw_calf);
+      // a foot farther from the plane than the margin has no active row (D = 0, aref = 0): skipped wave-wide on terrain
+      if (__ballot(c.dist - margin < 0.f) != 0ull) finish_contact(c, sr, si, margin, invw_calf);
+      else { c.row_active = false; c.D = 0.f; c.aref[0] = 0.f; c.aref[1] = 0.f; c.aref[2] = 0.f; c.aref[3] = 0.f; }
     }
     if (!has_boxes) return;
     float sr[2], si[5];
