@@ -1,0 +1,31 @@
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from phase_guided_terrain_traversal_amd import configs, abi
+from phase_guided_terrain_traversal_amd.env import Joystick
+from phase_guided_terrain_traversal_amd.randomize import domain_randomize
+from phase_guided_terrain_traversal_amd import mjcf
+assets = "phase_guided_terrain_traversal_amd/assets/terrains"
+for lay in ("hex", "quad"):
+    os.environ["PGTT_LAYOUT"] = lay
+    for level, dr in (("level13", True), ("level4", False)):
+        terrain = np.load(f"{assets}/{level}.npy"); n = 4096
+        kw = {}
+        if dr:
+            out = domain_randomize(mjcf.load_model("stairs"), n, seed=5, terrain=terrain)
+            kw = {"variant": torch.from_numpy(out["variant"]), "params": torch.from_numpy(out["params"]), "box_friction": torch.from_numpy(out["box_friction"])}
+        else:
+            kw = {"variant": torch.from_numpy(np.random.default_rng(1).integers(0, terrain.shape[0], n).astype(np.int32))}
+        env = Joystick("stairs", configs.training_config(), num_envs=n, terrain=terrain, device="cuda:0", autoreset=True, **kw)
+        env.reset(seed=9)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        dones = 0.0; bad = 0
+        for k in range(3000):
+            a = torch.tanh(torch.randn(n, 12, device="cuda", generator=g) * 0.8)
+            obs, r, d, info = env.step(a)
+            if k % 100 == 0:
+                dones += float(d.sum())
+                for key in ("state", "obs_state", "obs_priv", "reward", "metrics", "frame"):
+                    if not torch.isfinite(env.buffers[key]).all(): bad += 1
+        S = env.buffers["state"]
+        print(lay, level, "dr" if dr else "", "nonfinite checks failed:", bad, " |qpos z| max", float(S[2].abs().max()), " |qvel| max", float(S[19:37].abs().max()), " dones/100 steps sample", dones)
+        env.close()
