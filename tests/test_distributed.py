@@ -25,7 +25,10 @@ red = MetricReducer(torch.device("cpu"))
 g = torch.Generator().manual_seed(7)
 full_m = torch.rand(3, abi.NMETRIC, 1000, generator=g); full_r = torch.rand(3, 1000, generator=g); full_d = (torch.rand(3, 1000, generator=g) < 0.1).float()
 for k in range(3):
-    red.accumulate(full_m[k][:, lo:hi], full_r[k][lo:hi], full_d[k][lo:hi])
+    if k == 1:      # the one-kernel path bench.py uses: metrics, reward and done rows of one [24][n] block
+        red.accumulate_block(torch.cat([full_m[k][:, lo:hi], full_r[k][None, lo:hi], full_d[k][None, lo:hi]], 0))
+    else:
+        red.accumulate(full_m[k][:, lo:hi], full_r[k][lo:hi], full_d[k][lo:hi])
 out = red.reduce()
 exp_m = full_m.sum(0).sum(1) / 3000.0
 ok = torch.allclose(out["metrics_mean"], exp_m, atol=1e-5) and abs(float(out["reward_mean"]) - float(full_r.mean())) < 1e-5 \
