@@ -1328,7 +1328,7 @@ struct QSolver {
     rec_state(100.f);
 #endif
     const float scale = m->meaninertia * 18.0f;
-    int niter = 0;
+    int niter = 0, trip = 0;
     for (;;) {
       float gnb = 0.f, gnl = 0.f;
 #pragma unroll
@@ -1343,7 +1343,9 @@ struct QSolver {
       PG_TICK(s, 6);
       update_constraint();
       PG_TICK(s, 7);
-      update_gradient();
+      // "done" is sticky and every other lane counts up, so the loop makes at most `iterations` trips: the gradient,
+      // Hessian and search direction of the last possible trip would never be used (mjx computes them all the same)
+      if (++trip < m->iterations) update_gradient();
       PG_TICK(s, 8);
       s.cyc_iter();
       if (!done) niter++;
