@@ -1308,13 +1308,15 @@ struct QSolver {
     any_lim = __ballot(s.lim_active[0] || s.lim_active[1] || s.lim_active[2]) != 0ull;
     any_con0 = __ballot(s.con0.row_active) != 0ull;
     PG_TICK(s, 3);
-    init(s.wb, s.wl); update_constraint();
-    float cw = cost;
+    // start from the cheaper of (unconstrained acceleration, warm start).  The warm start is evaluated LAST: when it wins
+    // in every lane of the wave (the steady state) the solver state is already the one to continue from; only a wave
+    // in which some env prefers the unconstrained acceleration pays a third evaluation of the per-env choice.
     init(s.qas_b, s.qas_l); update_constraint();
-    if (__ballot(cw < cost) != 0ull) {
-      // warm start wins in at least one env of the wave: evaluate it for everybody, keep per env
+    const float cs = cost;
+    init(s.wb, s.wl); update_constraint();
+    const bool usew = cost < cs;
+    if (__ballot(!usew) != 0ull) {
       float kb[6], kl[3];
-      const bool usew = cw < cost;
 #pragma unroll
       for (int i = 0; i < 6; i++) kb[i] = usew ? s.wb[i] : s.qas_b[i];
 #pragma unroll
@@ -1341,11 +1343,14 @@ struct QSolver {
       PG_TICK(s, 9);
       linesearch(done);
       PG_TICK(s, 6);
-      update_constraint();
-      PG_TICK(s, 7);
-      // "done" is sticky and every other lane counts up, so the loop makes at most `iterations` trips: the gradient,
-      // Hessian and search direction of the last possible trip would never be used (mjx computes them all the same)
-      if (++trip < m->iterations) update_gradient();
+      // "done" is sticky and every other lane counts up, so the loop makes at most `iterations` trips: the constraint
+      // forces, cost, gradient, Hessian and search direction of the last possible trip would never be used (mjx
+      // computes them all the same); qacc is final after its line search
+      if (++trip < m->iterations) {
+        update_constraint();
+        PG_TICK(s, 7);
+        update_gradient();
+      }
       PG_TICK(s, 8);
       s.cyc_iter();
       if (!done) niter++;
