@@ -342,6 +342,110 @@ PG_INL float gait_get_z(float phi, float swing_height, float swing_min) {
   return cubic_hermite((phi - T_peak) / T_swing, swing_height, swing_min, T_swing * 0.f, T_swing * 0.f);
 }
 
+// Rewards, termination and bookkeeping of one control step (joystick_pgtt.py:193-227 / joystick.py): shared by the fused
+// observe kernel (sh_* in LDS) and by task_kernel (sh_* = per-lane arrays, all indices compile-time constants).
+struct TaskScalars {
+  float cmd[3], phase[4], air[4], peak[4], hmax[4], last_contact[4], contact[4], first_contact[4];
+  float phase_dt; int step_ctr, timer;
+  bool done; float reward; float metrics[PGTT_NMETRIC];
+};
+PG_INL void task_rewards(const float* sh_st, const float* sh_fr, const float* sh_act, const PgttConfig* __restrict__ cfg,
+                         const PgttModel* __restrict__ m, bool baseline, unsigned long long seed, unsigned id, unsigned ep, float dt,
+                         TaskScalars& t) {
+  float (&cmd)[3] = t.cmd; float (&phase)[4] = t.phase; float (&air)[4] = t.air; float (&peak)[4] = t.peak; float (&hmax)[4] = t.hmax;
+  float (&last_contact)[4] = t.last_contact; float (&contact)[4] = t.contact; float (&first_contact)[4] = t.first_contact;
+  float (&metrics)[PGTT_NMETRIC] = t.metrics;
+  const float phase_dt = t.phase_dt; int& step_ctr = t.step_ctr; int& timer = t.timer; bool& done = t.done; float& reward = t.reward;
+  struct { unsigned long long seed; } a{seed};
+    done = sh_fr[PGTT_F_UPVECTOR + 2] < 0.f;
+    float rew[PGTT_NREW];
+    const float cmd_norm = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1] + cmd[2] * cmd[2]);
+    {
+      float e0 = cmd[0] - sh_fr[PGTT_F_LOCAL_LINVEL], e1 = cmd[1] - sh_fr[PGTT_F_LOCAL_LINVEL + 1];
+      rew[PGTT_R_TRACKING_LIN_VEL] = expf(-(e0 * e0 + e1 * e1) / cfg->tracking_sigma);
+      float ea = cmd[2] - sh_fr[PGTT_F_GYRO + 2];
+      rew[PGTT_R_TRACKING_ANG_VEL] = expf(-(ea * ea) / cfg->tracking_sigma);
+    }
+    rew[PGTT_R_LIN_VEL_Z] = sh_fr[PGTT_F_GLOBAL_LINVEL + 2] * sh_fr[PGTT_F_GLOBAL_LINVEL + 2];
+    rew[PGTT_R_ANG_VEL_XY] = sh_fr[PGTT_F_GLOBAL_ANGVEL] * sh_fr[PGTT_F_GLOBAL_ANGVEL] + sh_fr[PGTT_F_GLOBAL_ANGVEL + 1] * sh_fr[PGTT_F_GLOBAL_ANGVEL + 1];
+    rew[PGTT_R_ORIENTATION] = sh_fr[PGTT_F_UPVECTOR] * sh_fr[PGTT_F_UPVECTOR] + sh_fr[PGTT_F_UPVECTOR + 1] * sh_fr[PGTT_F_UPVECTOR + 1];
+    {
+      float sa = 0.f, lim = 0.f, pose = 0.f, s2 = 0.f, s1 = 0.f, en = 0.f, ar = 0.f;
+#pragma unroll
+      for (int i = 0; i < 12; i++) {
+        float q = sh_st[PGTT_S_QPOS + 7 + i], dq = q - m->key_qpos[7 + i];
+        sa += fabsf(dq);
+        pose += (dq * dq) * ((i % 3) == 0 ? 1.0f : 0.1f);
+        float lo = m->jnt_range[i][0] * cfg->soft_joint_pos_limit_factor, hi = m->jnt_range[i][1] * cfg->soft_joint_pos_limit_factor;
+        lim += -fminf(q - lo, 0.f) + fmaxf(q - hi, 0.f);
+        float f = sh_fr[PGTT_F_ACT_FORCE + i];
+        s2 += f * f; s1 += fabsf(f);
+        en += fabsf(sh_st[PGTT_S_QVEL + 6 + i]) * fabsf(f);
+        float da = sh_act[i] - sh_st[PGTT_S_LAST_ACT + i]; ar += da * da;
+      }
+      rew[PGTT_R_STAND_STILL] = sa * (cmd_norm < 0.01f ? 1.f : 0.f);
+      rew[PGTT_R_POSE] = pose; rew[PGTT_R_DOF_POS_LIMITS] = lim;
+      rew[PGTT_R_TORQUES] = sqrtf(s2) + s1; rew[PGTT_R_ENERGY] = en; rew[PGTT_R_ACTION_RATE] = ar;
+    }
+    rew[PGTT_R_TERMINATION] = done ? 1.f : 0.f;
+    {
+      float slip = 0.f, clear = 0.f, perr = 0.f, swing = 0.f, airr = 0.f, con = 0.f, center = 0.f, fh = 0.f, minfoot = INFINITY;
+#pragma unroll
+      for (int f = 0; f < 4; f++) {
+        float vx = sh_fr[PGTT_F_FEET_VEL + 3 * f], vy = sh_fr[PGTT_F_FEET_VEL + 3 * f + 1];
+        float v2 = vx * vx + vy * vy;
+        slip += v2 * contact[f];
+        float px = sh_fr[PGTT_F_FEET_POS + 3 * f], py = sh_fr[PGTT_F_FEET_POS + 3 * f + 1], pz = sh_fr[PGTT_F_FEET_POS + 3 * f + 2];
+        const float clr = baseline ? sh_fr[PGTT_F_FOOT_SITE_Z + f] - (hmax[f] - cfg->base_feet_distance + cfg->swing_height)   // joystick.py:569-572
+                                   : pz - (hmax[f] + cfg->swing_height);                                                  // joystick_pgtt.py:576-578
+        clear += fabsf(clr) * sqrtf(sqrtf(v2));
+        float rz = gait_get_z(phase[f], hmax[f] + cfg->swing_height, cfg->base_feet_distance);
+        perr += (pz - rz) * (pz - rz);
+        bool swing_mask = phase[f] / (float)(2 * M_PI) >= 0.5f;
+        swing += ((pz - cfg->swing_height) * (pz - cfg->swing_height)) * (swing_mask ? 1.f : 0.f);
+        con += (swing_mask && contact[f] != 0.f) ? 1.f : 0.f;
+        airr += (air[f] - (baseline ? 0.5f : 0.1f)) * first_contact[f];        // joystick.py:591 / joystick_pgtt.py:597
+        center += px * px + py * py;
+        float er = peak[f] / cfg->swing_height - 1.0f;
+        fh += (er * er) * first_contact[f];
+        minfoot = fminf(minfoot, sh_fr[PGTT_F_FOOT_SITE_Z + f]);
+      }
+      float moving = cmd_norm > 0.01f ? 1.f : 0.f;
+      rew[PGTT_R_FEET_SLIP] = slip * moving; rew[PGTT_R_FEET_CLEARANCE] = clear;
+      rew[PGTT_R_FEET_PHASE] = expf(-perr / cfg->phase_sigma); rew[PGTT_R_FEET_SWING] = swing;
+      rew[PGTT_R_FEET_AIR_TIME] = airr * moving; rew[PGTT_R_CONTACT] = -con; rew[PGTT_R_CENTER] = center;
+      rew[PGTT_R_FEET_HEIGHT] = fh * moving;
+      float bh = sh_st[PGTT_S_QPOS + 2] - minfoot - 0.27f;
+      rew[PGTT_R_BODY_HEIGHT] = bh * bh;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < PGTT_NREW; k++) { metrics[k] = rew[k] * cfg->reward_scale[k]; sum += metrics[k]; }
+    reward = fminf(fmaxf(sum * dt, 0.f), 10000.f);
+    // bookkeeping (joystick_pgtt.py:205-227)
+    step_ctr += 1;
+#pragma unroll
+    for (int f = 0; f < 4; f++) phase[f] = fmodf(phase[f] + phase_dt, (float)(2 * M_PI));
+    timer -= 1;
+    if (timer <= 0) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        float y = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_Y, i) * (cfg->cmd_u_max[i] - cfg->cmd_u_min[i]) + cfg->cmd_u_min[i];
+        float zb = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_Z, i) < cfg->cmd_b[i] ? 1.f : 0.f;
+        float wb = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_W, i) < 0.5f ? 1.f : 0.f;
+        cmd[i] = cmd[i] - wb * (cmd[i] - y * zb);
+      }
+    }
+    if (done || timer <= 0) timer = exp_timer(a.seed, id, ep, PGTT_RS_TIMER, dt);
+    float sp = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+      float nc = contact[f] != 0.f ? 0.f : 1.f;
+      air[f] *= nc; peak[f] *= nc; last_contact[f] = contact[f]; sp += peak[f];
+    }
+    metrics[PGTT_NREW] = sp / 4;
+}
+
 template <int OMODE, bool HAS_TERRAIN>
 __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __restrict__ action) {
   const int e = xcd_block(blockIdx.x, gridDim.x), lane = threadIdx.x, N = a.N;
@@ -561,93 +665,20 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
   for (int k = 0; k < PGTT_NMETRIC; k++) metrics[k] = 0.f;
   float act_i = 0.f;
   if (OMODE == OBS_STEP) {
-    done = sh_fr[PGTT_F_UPVECTOR + 2] < 0.f;
-    float rew[PGTT_NREW];
-    const float cmd_norm = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1] + cmd[2] * cmd[2]);
-    {
-      float e0 = cmd[0] - sh_fr[PGTT_F_LOCAL_LINVEL], e1 = cmd[1] - sh_fr[PGTT_F_LOCAL_LINVEL + 1];
-      rew[PGTT_R_TRACKING_LIN_VEL] = expf(-(e0 * e0 + e1 * e1) / cfg->tracking_sigma);
-      float ea = cmd[2] - sh_fr[PGTT_F_GYRO + 2];
-      rew[PGTT_R_TRACKING_ANG_VEL] = expf(-(ea * ea) / cfg->tracking_sigma);
-    }
-    rew[PGTT_R_LIN_VEL_Z] = sh_fr[PGTT_F_GLOBAL_LINVEL + 2] * sh_fr[PGTT_F_GLOBAL_LINVEL + 2];
-    rew[PGTT_R_ANG_VEL_XY] = sh_fr[PGTT_F_GLOBAL_ANGVEL] * sh_fr[PGTT_F_GLOBAL_ANGVEL] + sh_fr[PGTT_F_GLOBAL_ANGVEL + 1] * sh_fr[PGTT_F_GLOBAL_ANGVEL + 1];
-    rew[PGTT_R_ORIENTATION] = sh_fr[PGTT_F_UPVECTOR] * sh_fr[PGTT_F_UPVECTOR] + sh_fr[PGTT_F_UPVECTOR + 1] * sh_fr[PGTT_F_UPVECTOR + 1];
-    {
-      float sa = 0.f, lim = 0.f, pose = 0.f, s2 = 0.f, s1 = 0.f, en = 0.f, ar = 0.f;
+    TaskScalars t;
 #pragma unroll
-      for (int i = 0; i < 12; i++) {
-        float q = sh_st[PGTT_S_QPOS + 7 + i], dq = q - m->key_qpos[7 + i];
-        sa += fabsf(dq);
-        pose += (dq * dq) * ((i % 3) == 0 ? 1.0f : 0.1f);
-        float lo = m->jnt_range[i][0] * cfg->soft_joint_pos_limit_factor, hi = m->jnt_range[i][1] * cfg->soft_joint_pos_limit_factor;
-        lim += -fminf(q - lo, 0.f) + fmaxf(q - hi, 0.f);
-        float f = sh_fr[PGTT_F_ACT_FORCE + i];
-        s2 += f * f; s1 += fabsf(f);
-        en += fabsf(sh_st[PGTT_S_QVEL + 6 + i]) * fabsf(f);
-        float da = sh_act[i] - sh_st[PGTT_S_LAST_ACT + i]; ar += da * da;
-      }
-      rew[PGTT_R_STAND_STILL] = sa * (cmd_norm < 0.01f ? 1.f : 0.f);
-      rew[PGTT_R_POSE] = pose; rew[PGTT_R_DOF_POS_LIMITS] = lim;
-      rew[PGTT_R_TORQUES] = sqrtf(s2) + s1; rew[PGTT_R_ENERGY] = en; rew[PGTT_R_ACTION_RATE] = ar;
-    }
-    rew[PGTT_R_TERMINATION] = done ? 1.f : 0.f;
-    {
-      float slip = 0.f, clear = 0.f, perr = 0.f, swing = 0.f, airr = 0.f, con = 0.f, center = 0.f, fh = 0.f, minfoot = INFINITY;
+    for (int i = 0; i < 3; i++) t.cmd[i] = cmd[i];
 #pragma unroll
-      for (int f = 0; f < 4; f++) {
-        float vx = sh_fr[PGTT_F_FEET_VEL + 3 * f], vy = sh_fr[PGTT_F_FEET_VEL + 3 * f + 1];
-        float v2 = vx * vx + vy * vy;
-        slip += v2 * contact[f];
-        float px = sh_fr[PGTT_F_FEET_POS + 3 * f], py = sh_fr[PGTT_F_FEET_POS + 3 * f + 1], pz = sh_fr[PGTT_F_FEET_POS + 3 * f + 2];
-        const float clr = baseline ? sh_fr[PGTT_F_FOOT_SITE_Z + f] - (hmax[f] - cfg->base_feet_distance + cfg->swing_height)   // joystick.py:569-572
-                                   : pz - (hmax[f] + cfg->swing_height);                                                  // joystick_pgtt.py:576-578
-        clear += fabsf(clr) * sqrtf(sqrtf(v2));
-        float rz = gait_get_z(phase[f], hmax[f] + cfg->swing_height, cfg->base_feet_distance);
-        perr += (pz - rz) * (pz - rz);
-        bool swing_mask = phase[f] / (float)(2 * M_PI) >= 0.5f;
-        swing += ((pz - cfg->swing_height) * (pz - cfg->swing_height)) * (swing_mask ? 1.f : 0.f);
-        con += (swing_mask && contact[f] != 0.f) ? 1.f : 0.f;
-        airr += (air[f] - (baseline ? 0.5f : 0.1f)) * first_contact[f];        // joystick.py:591 / joystick_pgtt.py:597
-        center += px * px + py * py;
-        float er = peak[f] / cfg->swing_height - 1.0f;
-        fh += (er * er) * first_contact[f];
-        minfoot = fminf(minfoot, sh_fr[PGTT_F_FOOT_SITE_Z + f]);
-      }
-      float moving = cmd_norm > 0.01f ? 1.f : 0.f;
-      rew[PGTT_R_FEET_SLIP] = slip * moving; rew[PGTT_R_FEET_CLEARANCE] = clear;
-      rew[PGTT_R_FEET_PHASE] = expf(-perr / cfg->phase_sigma); rew[PGTT_R_FEET_SWING] = swing;
-      rew[PGTT_R_FEET_AIR_TIME] = airr * moving; rew[PGTT_R_CONTACT] = -con; rew[PGTT_R_CENTER] = center;
-      rew[PGTT_R_FEET_HEIGHT] = fh * moving;
-      float bh = sh_st[PGTT_S_QPOS + 2] - minfoot - 0.27f;
-      rew[PGTT_R_BODY_HEIGHT] = bh * bh;
-    }
-    float sum = 0.f;
+    for (int f = 0; f < 4; f++) { t.phase[f] = phase[f]; t.air[f] = air[f]; t.peak[f] = peak[f]; t.hmax[f] = hmax[f]; t.last_contact[f] = last_contact[f]; t.contact[f] = contact[f]; t.first_contact[f] = first_contact[f]; }
+    t.phase_dt = phase_dt; t.step_ctr = step_ctr; t.timer = timer;
+    task_rewards(sh_st, sh_fr, sh_act, cfg, m, baseline, a.seed, id, ep, dt, t);
 #pragma unroll
-    for (int k = 0; k < PGTT_NREW; k++) { metrics[k] = rew[k] * cfg->reward_scale[k]; sum += metrics[k]; }
-    reward = fminf(fmaxf(sum * dt, 0.f), 10000.f);
-    // bookkeeping (joystick_pgtt.py:205-227)
-    step_ctr += 1;
+    for (int i = 0; i < 3; i++) cmd[i] = t.cmd[i];
 #pragma unroll
-    for (int f = 0; f < 4; f++) phase[f] = fmodf(phase[f] + phase_dt, (float)(2 * M_PI));
-    timer -= 1;
-    if (timer <= 0) {
+    for (int f = 0; f < 4; f++) { phase[f] = t.phase[f]; air[f] = t.air[f]; peak[f] = t.peak[f]; last_contact[f] = t.last_contact[f]; }
+    step_ctr = t.step_ctr; timer = t.timer; done = t.done; reward = t.reward;
 #pragma unroll
-      for (int i = 0; i < 3; i++) {
-        float y = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_Y, i) * (cfg->cmd_u_max[i] - cfg->cmd_u_min[i]) + cfg->cmd_u_min[i];
-        float zb = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_Z, i) < cfg->cmd_b[i] ? 1.f : 0.f;
-        float wb = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_W, i) < 0.5f ? 1.f : 0.f;
-        cmd[i] = cmd[i] - wb * (cmd[i] - y * zb);
-      }
-    }
-    if (done || timer <= 0) timer = exp_timer(a.seed, id, ep, PGTT_RS_TIMER, dt);
-    float sp = 0.f;
-#pragma unroll
-    for (int f = 0; f < 4; f++) {
-      float nc = contact[f] != 0.f ? 0.f : 1.f;
-      air[f] *= nc; peak[f] *= nc; last_contact[f] = contact[f]; sp += peak[f];
-    }
-    metrics[PGTT_NREW] = sp / 4;
+    for (int k = 0; k < PGTT_NMETRIC; k++) metrics[k] = t.metrics[k];
     if (lane < 12) act_i = sh_act[lane];
   }
   // ---------------- Episode / AutoReset wrapper semantics (UPSTREAM-RECALL)
