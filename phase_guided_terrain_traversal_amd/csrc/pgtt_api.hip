@@ -48,6 +48,7 @@ struct pgtt_env {
   long long env_off = 0;
   bool timing = false;
   int timing_period = 1, timing_tick = 0; bool timing_now = false;   // time every timing_period-th step (event records cost ~3 us of GPU idle each)
+  bool split_observe = false;     // observe = observe_kernel<OBS_STEP_OBS> + task_kernel (PGTT_OBSERVE=split|fused forces)
   int layout = 0;                 // lane layout of physics_kernel: 1 quad (16 envs per wave), 4 hex (4 envs per wave), 0 auto
   // kernel timing: a ring of event quadruples (physics begin / end, observe begin / end), one per step; a slot is
   // read back when it comes up for re-use (its step finished long ago: no stall) or by pgtt_kernel_ms_mean()
@@ -170,6 +171,10 @@ int pgtt_create(const PgttConfig* cfg, const PgttModel* model, int device, int n
     // lane layout: PGTT_LAYOUT=quad|hex forces one; default by batch size
     const char* lay = getenv("PGTT_LAYOUT");
     h->layout = (lay && !strcmp(lay, "hex")) ? 4 : ((lay && !strcmp(lay, "quad")) ? 1 : 0);
+    // observe as one kernel (every wave repeats the per-env scalar half: faster while the batch leaves SIMDs idle) or
+    // split into scan + observation rows (env per wave) and rewards / bookkeeping (env per lane): faster from ~16 k envs
+    const char* ob = getenv("PGTT_OBSERVE");
+    h->split_observe = (ob && !strcmp(ob, "split")) ? true : ((ob && !strcmp(ob, "fused")) ? false : num_envs >= 16384);
   }
   HIP_TRY(hipMalloc(&h->d_cfg, sizeof(PgttConfig)));
   HIP_TRY(hipMalloc(&h->d_model, sizeof(PgttModel)));
@@ -284,7 +289,13 @@ int pgtt_observe(pgtt_handle h, const float* action, void* stream) {
   pgtt::KArgs a = make_args(h, nullptr, 0.f);
   const bool timed = h->timing_now && h->ev_slot >= 0;
   if (timed) HIP_TRY(hipEventRecord(h->ev[h->ev_slot][2], st));
-  launch_observe<pgtt::OBS_STEP>(h, a, action, st);
+  if (h->split_observe) {
+    // scan + observation rows (one env per wave), then rewards / bookkeeping / wrapper (one env per lane)
+    launch_observe<pgtt::OBS_STEP_OBS>(h, a, action, st);
+    hipLaunchKernelGGL(pgtt::task_kernel<0>, dim3((h->N + 63) / 64), dim3(64), 0, st, a, action);
+  } else {
+    launch_observe<pgtt::OBS_STEP>(h, a, action, st);
+  }
   if (timed) { HIP_TRY(hipEventRecord(h->ev[h->ev_slot][3], st)); h->ev_used[h->ev_slot] = true; h->ev_valid = true; }
   HIP_TRY(hipGetLastError());
   return PGTT_OK;

@@ -298,7 +298,8 @@ __global__ __launch_bounds__(64) void reset_pose_kernel(KArgs a) {
 }
 
 // ------------------------------------------------------------------ observe: one env per wave
-enum { OBS_STEP = 0, OBS_SCAN_LIFT = 1, OBS_RESET = 2, OBS_SCAN_ONLY = 3 };
+// OBS_STEP_OBS: the scan + observation half of a step (rewards / bookkeeping are done by task_kernel, one env per LANE)
+enum { OBS_STEP = 0, OBS_SCAN_LIFT = 1, OBS_RESET = 2, OBS_SCAN_ONLY = 3, OBS_STEP_OBS = 4 };
 
 PG_INL float wave_max(float v) {
 #pragma unroll
@@ -449,7 +450,7 @@ PG_INL void task_rewards(const float* sh_st, const float* sh_fr, const float* sh
 template <int OMODE, bool HAS_TERRAIN>
 __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __restrict__ action) {
   const int e = xcd_block(blockIdx.x, gridDim.x), lane = threadIdx.x, N = a.N;
-  if (OMODE != OBS_STEP && a.mask && !a.mask[e]) return;
+  if (OMODE != OBS_STEP && OMODE != OBS_STEP_OBS && a.mask && !a.mask[e]) return;
   const PgttModel* __restrict__ m = a.model;
   const PgttConfig* __restrict__ cfg = a.cfg;
   float* __restrict__ S = a.buf.state;
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
   // ---------------- height scan (heightmap.py:25-67)
   const float bx = sh_st[PGTT_S_QPOS + 0], by = sh_st[PGTT_S_QPOS + 1], bz = sh_st[PGTT_S_QPOS + 2];
   float yaw;
-  if (OMODE == OBS_STEP || (OMODE == OBS_SCAN_ONLY && a.yaw_override != a.yaw_override)) {
+  if (OMODE == OBS_STEP || OMODE == OBS_STEP_OBS || (OMODE == OBS_SCAN_ONLY && a.yaw_override != a.yaw_override)) {
     float qw = sh_st[PGTT_S_QPOS + 3], qx = sh_st[PGTT_S_QPOS + 4], qy = sh_st[PGTT_S_QPOS + 5], qz = sh_st[PGTT_S_QPOS + 6];
     float qn = sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
     qw /= qn; qx /= qn; qy /= qn; qz /= qn;
@@ -658,6 +659,17 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
   __syncthreads();
   for (int i = lane; i < OBSD; i += 64) sh_obs[OBSD + i] = sh_obs[i];     // privileged = state || extras
   __syncthreads();
+  if (OMODE == OBS_STEP_OBS) {
+    // scan + observation half: H_max / H_min of this scan for task_kernel, the observation rows (a finished episode's
+    // rows are replaced by task_kernel), nothing else
+    if (lane < 4) {
+      S[(PGTT_S_HMAX + lane) * (long)N + e] = sel4(lane, hmax[0], hmax[1], hmax[2], hmax[3]);
+      S[(PGTT_S_HMIN + lane) * (long)N + e] = sel4(lane, hmin[0], hmin[1], hmin[2], hmin[3]);
+    }
+    for (int i = lane; i < OBSD; i += 64) a.buf.obs_state[(long)e * OBSD + i] = sh_obs[i];
+    for (int i = lane; i < PRIVD; i += 64) a.buf.obs_priv[(long)e * PRIVD + i] = sh_obs[OBSD + i];
+    return;
+  }
 
   // ---------------- rewards, termination, bookkeeping
   float reward = 0.f; bool done = false; float metrics[PGTT_NMETRIC];
@@ -744,6 +756,110 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
     if (a.buf.first_state) for (int r = lane; r < PGTT_S_CMD; r += 64) a.buf.first_state[r * (long)N + e] = sh_st[r];
     if (a.buf.first_obs) for (int i = lane; i < OBSD + PRIVD; i += 64) a.buf.first_obs[(long)e * (OBSD + PRIVD) + i] = sh_obs[i];
     if (a.buf.ep_metrics) for (int k = lane; k < PGTT_NMETRIC + 2; k += 64) a.buf.ep_metrics[k * (long)N + e] = 0.f;
+  }
+}
+
+
+// ------------------------------------------------------------------ task: one env per LANE (coalesced SoA rows)
+// The per-env scalar half of a control step: contact bookkeeping, the 21 rewards, termination, command resampling,
+// history buffers, Episode / AutoReset wrapper semantics.  In the fused observe kernel every wave repeats this ~2.5 k
+// instruction stream for ONE env; here a wave does it for 64.  Runs after observe_kernel<OBS_STEP_OBS>, which left
+// H_max / H_min of the current scan in the state rows and wrote the observation rows.
+template <int UNUSED>
+__global__ __launch_bounds__(64) void task_kernel(KArgs a, const float* __restrict__ action) {
+  const int N = a.N;
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= N) return;
+  const PgttModel* __restrict__ m = a.model;
+  const PgttConfig* __restrict__ cfg = a.cfg;
+  float* __restrict__ S = a.buf.state;
+  int* __restrict__ I = a.buf.istate;
+  const float* __restrict__ Fr = a.buf.frame;
+  // rows this half reads, as per-lane arrays with compile-time indices (registers)
+  float st[PGTT_NSTATE], fr[PGTT_NFRAME], act[12];
+#pragma unroll
+  for (int r = 0; r < PGTT_S_QWARM; r++) st[r] = S[r * (long)N + e];                      // qpos, qvel
+#pragma unroll
+  for (int r = PGTT_S_CMD; r < PGTT_NSTATE; r++) st[r] = S[r * (long)N + e];              // task rows
+#pragma unroll
+  for (int r = 0; r < PGTT_NFRAME; r++) fr[r] = Fr[r * (long)N + e];
+#pragma unroll
+  for (int i = 0; i < 12; i++) act[i] = action[(long)e * 12 + i];
+  const bool baseline = cfg->method == PGTT_METHOD_BASELINE;
+  const int OBSD = baseline ? PGTT_OBS_BASELINE : PGTT_OBS, PRIVD = OBSD + (PGTT_PRIV - PGTT_OBS);
+  const unsigned id = (unsigned)(a.env_off + e);
+  const unsigned ep = (unsigned)I[PGTT_I_RNG_CTR * (long)N + e];
+  int ep_steps = I[PGTT_I_EP_STEPS * (long)N + e];
+  const float dt = cfg->ctrl_dt;
+  const bool prev_done = cfg->autoreset && a.buf.done[e] != 0.f;
+  if (prev_done) ep_steps = 0;
+  TaskScalars t;
+  t.step_ctr = I[PGTT_I_STEP * (long)N + e]; t.timer = I[PGTT_I_STEPS_UNTIL_CMD * (long)N + e];
+#pragma unroll
+  for (int i = 0; i < 3; i++) t.cmd[i] = st[PGTT_S_CMD + i];
+  t.phase_dt = st[PGTT_S_PHASE_DT];
+#pragma unroll
+  for (int f = 0; f < 4; f++) {
+    t.phase[f] = st[PGTT_S_PHASE + f];
+    t.last_contact[f] = st[PGTT_S_LAST_CONTACT + f];
+    t.contact[f] = fr[PGTT_F_CONTACT + f];
+    const bool filt = (t.contact[f] != 0.f) || (t.last_contact[f] != 0.f);
+    t.first_contact[f] = (st[PGTT_S_AIR_TIME + f] > 0.f ? 1.f : 0.f) * (filt ? 1.f : 0.f);
+    t.air[f] = st[PGTT_S_AIR_TIME + f] + dt;
+    t.peak[f] = fmaxf(st[PGTT_S_SWING_PEAK + f], fr[PGTT_F_FEET_POS + 3 * f + 2]);
+    t.hmax[f] = st[PGTT_S_HMAX + f];                                                     // of the current scan
+  }
+  // history buffers (joystick_pgtt.py:319-334) use the step counter BEFORE it advances
+  float hist_q[24], hist_v[24];
+  const bool upd = (t.step_ctr % cfg->history_update_steps) == 0;
+#pragma unroll
+  for (int i = 0; i < 24; i++) {
+    const float nv = i < 12 ? st[PGTT_S_QVEL + 6 + (i < 12 ? i : 0)] : st[PGTT_S_QVEL_HIST + (i >= 12 ? i - 12 : 0)];
+    const float nq = i < 12 ? st[PGTT_S_QPOS + 7 + (i < 12 ? i : 0)] - st[PGTT_S_MOTOR_TARGETS + (i < 12 ? i : 0)] : st[PGTT_S_QERR_HIST + (i >= 12 ? i - 12 : 0)];
+    hist_v[i] = upd ? nv : st[PGTT_S_QVEL_HIST + i];
+    hist_q[i] = upd ? nq : st[PGTT_S_QERR_HIST + i];
+  }
+  task_rewards(st, fr, act, cfg, m, baseline, a.seed, id, ep, dt, t);
+  // Episode / AutoReset wrapper semantics
+  bool wdone = t.done;
+  if (cfg->autoreset) {
+    ep_steps += 1;
+    if (ep_steps >= cfg->episode_length) wdone = true;
+    if (a.buf.ep_metrics) {
+      const float keep = prev_done ? 0.f : 1.f;
+#pragma unroll
+      for (int k = 0; k < PGTT_NMETRIC + 2; k++) {
+        const float add = k < PGTT_NMETRIC ? t.metrics[k < PGTT_NMETRIC ? k : 0] : (k == PGTT_NMETRIC ? t.reward : 1.0f);
+        float* p = a.buf.ep_metrics + k * (long)N + e;
+        *p = (*p + add) * keep;
+      }
+    }
+  }
+  // stores
+#pragma unroll
+  for (int i = 0; i < 3; i++) S[(PGTT_S_CMD + i) * (long)N + e] = t.cmd[i];
+#pragma unroll
+  for (int f = 0; f < 4; f++) {
+    S[(PGTT_S_PHASE + f) * (long)N + e] = t.phase[f];
+    S[(PGTT_S_AIR_TIME + f) * (long)N + e] = t.air[f];
+    S[(PGTT_S_SWING_PEAK + f) * (long)N + e] = t.peak[f];
+    S[(PGTT_S_LAST_CONTACT + f) * (long)N + e] = t.last_contact[f];
+  }
+#pragma unroll
+  for (int i = 0; i < 24; i++) { S[(PGTT_S_QVEL_HIST + i) * (long)N + e] = hist_v[i]; S[(PGTT_S_QERR_HIST + i) * (long)N + e] = hist_q[i]; }
+#pragma unroll
+  for (int i = 0; i < 12; i++) { S[(PGTT_S_LAST_LAST_ACT + i) * (long)N + e] = st[PGTT_S_LAST_ACT + i]; S[(PGTT_S_LAST_ACT + i) * (long)N + e] = act[i]; }
+  I[PGTT_I_STEP * (long)N + e] = t.step_ctr; I[PGTT_I_STEPS_UNTIL_CMD * (long)N + e] = t.timer;
+  I[PGTT_I_RNG_CTR * (long)N + e] = (int)(ep + 1u); I[PGTT_I_EP_STEPS * (long)N + e] = ep_steps;
+  a.buf.reward[e] = t.reward; a.buf.done[e] = wdone ? 1.f : 0.f;
+#pragma unroll
+  for (int k = 0; k < PGTT_NMETRIC; k++) a.buf.metrics[k * (long)N + e] = t.metrics[k];
+  // AutoReset: a finished episode continues from the env's first state and first observation
+  if (cfg->autoreset && wdone && a.buf.first_state && a.buf.first_obs) {
+    for (int r = 0; r < PGTT_S_CMD; r++) S[r * (long)N + e] = a.buf.first_state[r * (long)N + e];
+    const float* fo = a.buf.first_obs + (long)e * (OBSD + PRIVD);
+    for (int i = 0; i < OBSD; i++) a.buf.obs_state[(long)e * OBSD + i] = fo[i];
+    for (int i = 0; i < PRIVD; i++) a.buf.obs_priv[(long)e * PRIVD + i] = fo[OBSD + i];
   }
 }
 

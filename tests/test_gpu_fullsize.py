@@ -76,7 +76,9 @@ def test_masked_reset_leaves_other_envs_untouched():
     env.close()
 
 
-def test_episode_and_autoreset_semantics():
+@pytest.mark.parametrize("observe", ["fused", "split"])
+def test_episode_and_autoreset_semantics(observe, monkeypatch):
+    monkeypatch.setenv("PGTT_OBSERVE", observe)
     cfg = configs.with_overrides(configs.training_config(), episode_length=7)
     env, _, _ = make(n=512, cfg=cfg, variant=np.zeros(512, dtype=np.int32))
     env.reset(seed=5)

@@ -208,6 +208,15 @@ def test_baseline_method_parity():
     env.close()
 
 
+def test_split_observe_parity(monkeypatch):
+    """observe as two kernels (scan + observation rows per wave, rewards / bookkeeping / AutoReset per lane), the path
+    taken from 16 k envs: same parity bar, AutoReset included"""
+    monkeypatch.setenv("PGTT_OBSERVE", "split")
+    terrain = np.load(os.path.join(ASSETS, "terrains", "level13.npy"))
+    run_parity("stairs", 128, terrain, steps=40, dr=True, autoreset=True)
+    run_parity("flat_terrain", 100, None, steps=20, autoreset=True, method="baseline")
+
+
 def test_library_refuses_without_bind():
     import ctypes as C
     from phase_guided_terrain_traversal_amd import native
