@@ -27,7 +27,9 @@ from . import abi
 
 
 def domain_randomize(model: Dict[str, Any], num_envs: int, seed: int = 0, terrain: Optional[np.ndarray] = None,
-                     env_id_offset: int = 0, enable: bool = True) -> Dict[str, np.ndarray]:
+                     env_id_offset: int = 0, enable: bool = True, _frac: Optional[float] = None) -> Dict[str, np.ndarray]:
+    """`_frac` (tests only): every draw returns lo + _frac * (hi - lo) instead of a Philox sample, which is how
+    tests/golden/domain_randomize.npz was recorded from the reference's own functions."""
     n = int(num_envs)
     P = np.zeros((abi.NPARAM, n), dtype=np.float32)
     nbox = 0 if terrain is None else terrain.shape[1]
@@ -37,7 +39,10 @@ def domain_randomize(model: Dict[str, Any], num_envs: int, seed: int = 0, terrai
     mass0 = np.asarray(model["body_mass"], dtype=np.float64)
     for e in range(n):
         g = np.random.Generator(np.random.Philox(key=[int(seed), int(env_id_offset + e)]))
-        u = lambda lo, hi, size=None: g.uniform(lo, hi, size)
+        if _frac is None:
+            u = lambda lo, hi, size=None: g.uniform(lo, hi, size)
+        else:
+            u = lambda lo, hi, size=None: (lo + _frac * (hi - lo)) * (np.ones(size) if size is not None else 1.0)
         floor_fr = u(0.4, 1.0)                                   # drawn in both variants
         if nbox:
             bf = u(0.4, 1.0, nbox)
@@ -65,7 +70,7 @@ def domain_randomize(model: Dict[str, Any], num_envs: int, seed: int = 0, terrai
         P[abi.P_BIAS1:abi.P_BIAS1 + 12, e] = np.asarray(model["act_bias"])[:, 1] * dgain
         P[abi.P_FLOOR_FRICTION, e] = floor_fr
         if nbox:
-            variant[e] = int(g.integers(0, T))
+            variant[e] = int(g.integers(0, T)) if _frac is None else int(_frac * (T - 1))
             if enable:
                 box_friction[:nbox, e] = bf
     out = {"params": P, "variant": variant}

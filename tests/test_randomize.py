@@ -43,3 +43,30 @@ def test_disabled_is_nominal():
     P = domain_randomize(m, 4, seed=2, enable=False)["params"]
     assert np.allclose(P[abi.P_BODY_MASS:abi.P_BODY_MASS + 13], m["body_mass"][:, None])
     assert np.allclose(P[abi.P_GAIN:abi.P_GAIN + 12], 40)
+
+
+def test_formulas_against_reference_fixture():
+    """go2/randomize.py and randomize_simple.py executed by the reference's own Python on a numpy stand-in of the model
+    with every uniform draw pinned to lo + f (hi - lo), f in {0, 0.5, 1} (tools/gen_golden.py): same 12 fields here."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "domain_randomize.npz"))
+    T = int(g["nvariants"])
+    terr = np.zeros((T, 100, 10), dtype=np.float32)
+    for task, name, terrain in (("stairs", "stairs", terr), ("flat_terrain", "flat", None)):
+        m = mjcf.load_model(task)
+        for f in (0.0, 0.5, 1.0):
+            k = f"{name}_f{int(f * 2)}_"
+            out = domain_randomize(m, 3, seed=9, terrain=terrain, _frac=f)
+            P = out["params"][:, 1]
+            tol = dict(rtol=2e-6, atol=1e-7)
+            assert np.allclose(P[abi.P_BODY_MASS:abi.P_BODY_MASS + 13], g[k + "body_mass"], **tol), (k, "mass")
+            assert np.allclose(P[abi.P_BASE_IPOS:abi.P_BASE_IPOS + 3], g[k + "body_ipos"], **tol)
+            assert np.allclose(P[abi.P_QPOS0:abi.P_QPOS0 + 12], g[k + "qpos0"], **tol)
+            assert np.allclose(P[abi.P_ARMATURE:abi.P_ARMATURE + 12], g[k + "armature"], **tol)
+            assert np.allclose(P[abi.P_DAMPING:abi.P_DAMPING + 12], g[k + "damping"], **tol)
+            assert np.allclose(P[abi.P_GAIN:abi.P_GAIN + 12], g[k + "gain"], **tol)
+            assert np.allclose(P[abi.P_BIAS1:abi.P_BIAS1 + 12], g[k + "bias1"], **tol)
+            assert np.isclose(P[abi.P_FLOOR_FRICTION], g[k + "floor_friction"], **tol), (k, "floor friction")
+            assert np.all(g[k + "frictionloss"] == 0.0)            # nominal frictionloss is 0: its scaling is a no-op
+            if terrain is not None:
+                assert np.allclose(out["box_friction"][:100, 1], g[k + "box_friction"], **tol)
+                assert out["variant"][1] == int(g[k + "variant"])
