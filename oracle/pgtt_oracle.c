@@ -25,10 +25,12 @@ static inline void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c[4]) {
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
 }
-static int g_rng_override = 0;   /* tests only: every uniform draw returns 0.5 (fixtures generated with stubbed jax.random) */
-void pgtt_oracle_set_rng_override(int on) { g_rng_override = on; }
+static int g_rng_override = 0;   /* tests only: every uniform draw returns g_rng_value (fixtures generated with stubbed jax.random) */
+static float g_rng_value = 0.5f;
+void pgtt_oracle_set_rng_override(int on) { g_rng_override = on; g_rng_value = 0.5f; }
+void pgtt_oracle_set_rng_override_value(float v) { g_rng_override = 1; g_rng_value = v; }
 static inline float pgtt_philox_uniform(uint64_t seed, uint32_t env, uint32_t epoch, uint32_t stream, int idx) {
-  if (g_rng_override) return 0.5f;
+  if (g_rng_override) return g_rng_value;
   uint32_t c[4] = {env, epoch, stream, (uint32_t)(idx >> 2)};
   philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), c);
   return (float)(c[idx & 3] >> 8) * (1.0f / 16777216.0f);

@@ -121,3 +121,47 @@ def test_task_step_against_reference(golden_dir, ms, fp64, method):
         assert np.array_equal(S[abi.S_LAST_CONTACT:abi.S_LAST_CONTACT + 4], k("out_last_contact")), i
         assert I[abi.I_STEP] == int(k("out_step")), i
         assert I[abi.I_STEPS_UNTIL_CMD] == int(k("out_steps_until_next_cmd")), (i, I[abi.I_STEPS_UNTIL_CMD], k("out_steps_until_next_cmd"))
+
+
+@pytest.mark.parametrize("fp64", [True, False])
+def test_task_reset_against_reference(golden_dir, fp64):
+    """Joystick.reset (joystick_pgtt.py:50-131 / joystick.py) run by tools/gen_golden.py with every draw pinned to a
+    fraction f of its range: spawn offset, yaw (and the order of the quaternion product, on a tilted keyframe), initial
+    velocity, the lift by the highest scan point, command / gait-frequency / timer draws and the info initial values."""
+    g = np.load(os.path.join(golden_dir, "task_reset.npz"))
+    L = oracle.lib()
+    L.pgtt_oracle_set_rng_override_value.argtypes = [C.c_float]
+    tol = 2e-7 if fp64 else 3e-6
+    slab = np.zeros((1, 100, 10), dtype=np.float32)
+    slab[0, :, 3] = 1.0
+    slab[0, 0, :3] = [0.0, 0.0, 0.06]; slab[0, 0, 7:] = [6.0, 6.0, 0.06]          # top face at z = 0.12 under the whole footprint
+    slab[0, 1:, :3] = [50.0, 50.0, -1.0]; slab[0, 1:, 7:] = 0.01
+    models = {0.0: mjcf.load_model("flat_terrain"), 0.12: mjcf.load_model("stairs")}
+    try:
+        for i in range(int(g["ncases"])):
+            k = lambda n: g[f"r{i}_{n}"]
+            method, f, top = str(k("method")), float(k("frac")), float(k("top"))
+            cs = abi.config_struct(configs.training_config(method))
+            model = dict(models[top]); model["key_qpos"] = np.asarray(k("init_q"), dtype=np.float64)
+            ms = abi.model_struct(model)
+            hb = oracle.HostBuffers(1, method=method)
+            L.pgtt_oracle_set_rng_override_value(C.c_float(f))
+            oracle.reset(cs, ms, slab if top else None, hb, seed=3, fp64=fp64)
+            S, I = hb["state"][:, 0].astype(np.float64), hb["istate"][:, 0]
+            assert np.abs(S[abi.S_QPOS:abi.S_QPOS + 19] - k("qpos")).max() < tol, i
+            assert np.abs(S[abi.S_QVEL:abi.S_QVEL + 18] - k("qvel")).max() < tol, i
+            # the scan is taken at the spawn pose, then again (for info) at the lifted one, both with yaw 0
+            assert np.allclose(k("scan_centers")[1, 2] - k("scan_centers")[0, 2], top) and not k("scan_yaws").any()
+            assert np.abs(S[abi.S_CMD:abi.S_CMD + 3] - k("info_command")).max() < tol, i
+            assert abs(S[abi.S_GAIT_FREQ] - k("info_gait_freq")) < tol and abs(S[abi.S_PHASE_DT] - k("info_phase_dt")) < tol
+            assert np.abs(S[abi.S_PHASE:abi.S_PHASE + 4] - k("info_phase")).max() < 1e-6
+            assert I[abi.I_STEPS_UNTIL_CMD] == int(k("info_steps_until_next_cmd")) and I[abi.I_STEP] == int(k("info_step")) == 0
+            for off, n, name in ((abi.S_LAST_ACT, 12, "last_act"), (abi.S_LAST_LAST_ACT, 12, "last_last_act"),
+                                 (abi.S_AIR_TIME, 4, "feet_air_time"), (abi.S_SWING_PEAK, 4, "swing_peak"),
+                                 (abi.S_HMAX, 4, "H_max"), (abi.S_HMIN, 4, "H_min"), (abi.S_MOTOR_TARGETS, 12, "motor_targets"),
+                                 (abi.S_QERR_HIST, 24, "qpos_error_history"), (abi.S_QVEL_HIST, 24, "qvel_history"),
+                                 (abi.S_LAST_CONTACT, 4, "last_contact")):
+                assert np.abs(S[off:off + n] - k("info_" + name)).max() < 1e-7, (i, name)
+            assert float(k("reward")) == 0.0 and float(k("done")) == 0.0 and float(k("metrics_sum")) == 0.0
+    finally:
+        L.pgtt_oracle_set_rng_override(0)

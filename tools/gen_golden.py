@@ -91,7 +91,7 @@ FRAC = [0.5]      # every uniform draw returns minval + FRAC * (maxval - minval)
 jrandom.uniform = lambda key, shape=(), minval=0.0, maxval=1.0: (FRAC[0] * (np.asarray(maxval) - np.asarray(minval)) + np.asarray(minval)) * np.ones(shape)
 jrandom.randint = lambda key, shape=(), minval=0, maxval=1: (int(minval) + int(FRAC[0] * (int(maxval) - int(minval) - 1))) * np.ones(shape, dtype=np.int64)
 jrandom.bernoulli = lambda key, p=0.5, shape=(): (0.5 < np.asarray(p)) * np.ones(shape, dtype=bool)
-jrandom.exponential = lambda key, shape=(): -np.log1p(-0.5) * np.ones(shape)
+jrandom.exponential = lambda key, shape=(): -np.log1p(-FRAC[0]) * np.ones(shape)
 jrandom.PRNGKey = lambda s: np.zeros(2, dtype=np.uint32)
 
 jax = types.ModuleType("jax")
@@ -430,6 +430,88 @@ for f in (0.0, 0.5, 1.0):
 FRAC[0] = 0.5
 np.savez(os.path.join(OUT, "domain_randomize.npz"), nvariants=terr.shape[0], **dr_rec)
 print("domain_randomize fixture:", len(dr_rec), "arrays")
+
+# ------------------------------------------------------------------ episode reset (a14): Joystick.reset, joystick_pgtt.py:50-131
+# The reference's reset run with every uniform draw pinned to minval + f * (maxval - minval) and the exponential to
+# -log1p(-f).  mjx_env.init / mjx.forward are identity stand-ins (the physics is MJX's, not the reference's); the two
+# quaternion helpers of mujoco/mjx/_src/math.py (un-vendored) are restated from their published definitions: axis-angle
+# to unit quaternion, Hamilton product.  The height scan returns a constant top height so the lift is visible.
+def _axis_angle_to_quat(axis, angle):
+    a = float(np.asarray(angle).reshape(-1)[0])
+    return np.concatenate([[np.cos(a / 2)], np.asarray(axis, dtype=np.float64) * np.sin(a / 2)]).view(AtArray)
+
+
+def _quat_mul(u, v):
+    return np.array([u[0] * v[0] - u[1] * v[1] - u[2] * v[2] - u[3] * v[3],
+                     u[0] * v[1] + u[1] * v[0] + u[2] * v[3] - u[3] * v[2],
+                     u[0] * v[2] - u[1] * v[3] + u[2] * v[0] + u[3] * v[1],
+                     u[0] * v[3] + u[1] * v[2] - u[2] * v[1] + u[3] * v[0]]).view(AtArray)
+
+
+mjx_math.axis_angle_to_quat = _axis_angle_to_quat; mjx_math.quat_mul = _quat_mul
+
+
+class _ResetData:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def replace(self, **kw):
+        d = _ResetData(**self.__dict__); d.__dict__.update(kw); return d
+
+
+INIT_LOG = []
+
+
+def _init(model, qpos=None, qvel=None, ctrl=None):
+    INIT_LOG.append((np.array(qpos), np.array(qvel), np.array(ctrl)))
+    # placeholder sensor outputs: _get_obs runs for its side effects on info (the history update at step 0)
+    return _ResetData(qpos=qpos, qvel=qvel, ctrl=ctrl, sensordata=np.zeros(49), site_xmat=np.stack([np.eye(3)] * 5),
+                      site_xpos=np.zeros((5, 3)), actuator_force=np.zeros(12), xfrc_applied=np.zeros((14, 6)))
+
+
+mpe.init = _init
+mjx.forward = lambda model, data: data
+MjxEnv.mjx_model = property(lambda self: self._mjx_model)
+reset_rec = {}
+tilt = np.array([0.97, 0.05, -0.12, 0.2]); tilt /= np.linalg.norm(tilt)     # a tilted keyframe pins the order of the quaternion product
+init_qs = [np.concatenate([[0.0, 0.0, 0.27], [1.0, 0, 0, 0], default_pose]), np.concatenate([[0.3, -0.2, 0.33], tilt, default_pose + 0.1])]
+n_reset = 0
+for mod, cfg_r, tag in ((jpg, cfg, "pgtt"), (jbase, cfg_b, "baseline")):
+    for f in (0.0, 0.25, 0.5, 0.9):
+        for qi, init_q in enumerate(init_qs):
+            for top in (0.0, 0.12):
+                FRAC[0] = f
+                env = make_env(mod, cfg_r)
+                env._init_q = init_q.view(AtArray)
+                env._mjx_model = types.SimpleNamespace(nv=18, nu=12)
+                env.init_feet_pos = np.zeros((4, 3)).view(AtArray)
+                env.get_feet_pos = lambda data: np.zeros((4, 3))
+                env.compute_contact = lambda data, a, b: np.zeros(4, dtype=bool)
+                centers = []
+
+                def _scan(mx, dx, center, yaw=0.0, top=top, centers=centers):
+                    centers.append((np.array(center, dtype=np.float64), float(yaw)))
+                    out = np.zeros((13, 9, 3)); out[..., 2] = top
+                    out[6, 4, 2] = top - 0.01          # not every ray sees the top: the lift uses the maximum
+                    return out.view(AtArray)
+                mod.create_sensor_matrix = _scan
+                INIT_LOG.clear()
+                st = env.reset(np.zeros(2, dtype=np.uint32))
+                k = f"r{n_reset}_"
+                reset_rec[k + "method"] = tag; reset_rec[k + "frac"] = f; reset_rec[k + "init_q"] = init_q; reset_rec[k + "top"] = top
+                reset_rec[k + "init_qpos"], reset_rec[k + "init_qvel"], reset_rec[k + "init_ctrl"] = INIT_LOG[0]
+                reset_rec[k + "qpos"] = np.asarray(st.data.qpos, dtype=np.float64); reset_rec[k + "qvel"] = np.asarray(st.data.qvel, dtype=np.float64)
+                reset_rec[k + "scan_centers"] = np.array([c for c, _ in centers]); reset_rec[k + "scan_yaws"] = np.array([y for _, y in centers])
+                for name, v in st.info.items():
+                    if name not in ("rng", "heightscan"):
+                        reset_rec[k + "info_" + name] = np.array(v, dtype=np.float64)
+                reset_rec[k + "reward"] = float(st.reward); reset_rec[k + "done"] = float(st.done)
+                reset_rec[k + "metrics_keys"] = np.array(sorted(st.metrics.keys()))
+                reset_rec[k + "metrics_sum"] = float(sum(float(v) for v in st.metrics.values()))
+                n_reset += 1
+FRAC[0] = 0.5
+np.savez(os.path.join(OUT, "task_reset.npz"), ncases=n_reset, **reset_rec)
+print("task_reset fixture:", n_reset, "cases")
 
 # ------------------------------------------------------------------ terrain generator (N3): tile geometry, adjacency rules, WFC samples
 import random as _random
