@@ -62,16 +62,16 @@ struct pgtt_env {
 
 #if defined(PGTT_TRACE) || defined(PGTT_TIME)
 static float* g_trace = nullptr;
-static int g_trace_launch = 0;      // every physics launch records into its own 16384-float segment (mod 4)
+static int g_trace_launch = 0;      // every physics launch records into its own 65536-float segment (mod 4)
 static float* pgtt_trace_buffer() {
-  if (!g_trace) { hipMalloc(&g_trace, 65536 * sizeof(float)); hipMemset(g_trace, 0, 65536 * sizeof(float)); }
+  if (!g_trace) { hipMalloc(&g_trace, 262144 * sizeof(float)); hipMemset(g_trace, 0, 262144 * sizeof(float)); }
   return g_trace;
 }
 extern "C" int pgtt_trace_read(float* host, int n) {
   hipDeviceSynchronize();
   return (int)hipMemcpy(host, pgtt_trace_buffer(), n * sizeof(float), hipMemcpyDeviceToHost);
 }
-extern "C" void pgtt_trace_clear() { hipDeviceSynchronize(); hipMemset(pgtt_trace_buffer(), 0, 65536 * sizeof(float)); g_trace_launch = 0; }
+extern "C" void pgtt_trace_clear() { hipDeviceSynchronize(); hipMemset(pgtt_trace_buffer(), 0, 262144 * sizeof(float)); g_trace_launch = 0; }
 #endif
 
 namespace {
@@ -101,7 +101,7 @@ template <int MODE>
 void launch_physics(pgtt_env* h, const pgtt::KArgs& a_in, const float* action, hipStream_t st) {
   pgtt::KArgs a = a_in;
 #if defined(PGTT_TRACE) || defined(PGTT_TIME)
-  a.trace = pgtt_trace_buffer() + 16384 * (g_trace_launch++ & 3);
+  a.trace = pgtt_trace_buffer() + 65536 * (g_trace_launch++ & 3);
 #endif
   // quad layout: 16 envs per 64-thread block; hex layout: 4 envs per block (pgtt_physics_quad.hip.h)
   const bool dr = h->buf.params != nullptr, terr = h->T > 0;

@@ -71,6 +71,9 @@ template <int MODE, bool HAS_DR, bool HAS_TERRAIN, int SUBS>
 __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __restrict__ action) {
   static_assert(SUBS == kSubs, "one lane layout per translation unit");
   const int N = a.N;
+#ifdef PGTT_TIME
+  const long long t0_cyc = __builtin_readcyclecounter(), t0_real = wall_clock64();
+#endif
   const int l = (threadIdx.x / kSubs) & 3;             // leg FL,FR,RL,RR
   const int blk = xcd_block(blockIdx.x, gridDim.x);
   int e = blk * kEnvsPerWave + (threadIdx.x / (4 * kSubs));
@@ -87,6 +90,9 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   QEnvModel em;
   qload_env_model<HAS_DR>(m, a.buf.params, N, e, l, em);
   QSim s;
+#ifdef PGTT_TIME
+  s.tlast = t0_cyc;
+#endif
 #pragma unroll
   for (int i = 0; i < 7; i++) s.qb[i] = S[(PGTT_S_QPOS + i) * (long)N + e];
 #pragma unroll
@@ -235,12 +241,23 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
 #ifdef PGTT_TIME
   // stage ticks of the wave that owns env PGTT_TIME (e.g. -DPGTT_TIME=0): 0 position 1 velocity 2 constraint 3 sensors
   // 4 solver init x3 5 first gradient 6 line search 7 update_constraint 8 update_gradient 9 rest 10 #iterations
-  if (e == PGTT_TIME && a.trace) for (int i = 0; i < 20; i++) a.trace[i] = s.cyc[i];
+  if (e == PGTT_TIME && a.trace) {
+    for (int i = 0; i < 20; i++) a.trace[i] = s.cyc[i];
+    // whole-kernel span of this wave in shader-clock ticks and in ticks of the constant 100 MHz clock (gives the shader clock rate)
+    a.trace[20] = (float)(__builtin_readcyclecounter() - t0_cyc); a.trace[21] = (float)(wall_clock64() - t0_real);
+  }
   if (a.trace) {      // per-wave totals: [32 + block] ticks of the whole kernel, [32 + 4096 + block] sum over substeps of nslots
     float tot = 0.f;
     for (int i = 0; i < 10; i++) tot += i == 9 ? 0.f : s.cyc[i];
     for (int i = 11; i < 17; i++) tot += s.cyc[i];
     a.trace[32 + blockIdx.x] = tot; a.trace[32 + 4096 + blockIdx.x] = s.cyc[17];
+    // placement and timeline of the wave (blocks < 1024): HW_ID, XCC_ID, start / end on the constant 100 MHz clock
+    if (blockIdx.x < 1024) {
+      unsigned* tw = (unsigned*)(a.trace + 32 + 8192 + 4 * blockIdx.x);
+      tw[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4); tw[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+      tw[2] = (unsigned)t0_real; tw[3] = (unsigned)wall_clock64();
+      for (int i = 0; i < 20; i++) a.trace[16384 + 24 * blockIdx.x + i] = s.cyc[i];      // stage ticks of every wave
+    }
   }
 #endif
   if (!valid) return;

@@ -808,25 +808,37 @@ struct QPhysics {
       need_exact = quad_sum_i(sub_sum_i(cnt)) > maxp;
     }
     if (broad && __ballot(need_exact) != 0ull) {
-      // pass 2b (rare): exact broad-phase rank = number of the 400 (foot, box) pairs that sort before the candidate;
-      // every lane counts over its own foot's pairs, the quad sum gives the rank
-#pragma unroll 4
-      for (int b = 0; b < nbox; b++) {
+      // pass 2b (rare, but the wave that takes it is the one the launch waits for): exact broad-phase rank = number of
+      // the 400 (foot, box) pairs that sort before the candidate by (key, index).  The pair (key, index) is packed into
+      // one 64-bit integer (key through the order-preserving float -> uint map; keys are never -0 or NaN), so a
+      // candidate costs one compare and one add per box; every lane counts over its own foot's pairs (hex: the boxes
+      // go round the sub-lanes), the sums over the lanes of the env give the ranks.
+      auto packed = [](float key, int idx) {
+        const unsigned u = __float_as_uint(key);
+        const unsigned mono = u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
+        return ((unsigned long long)mono << 32) | (unsigned)idx;
+      };
+      unsigned long long cpk[4][kMaxPenQ];
+#pragma unroll
+      for (int i = 0; i < kMaxPenQ; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) cpk[j][i] = packed(ckey[j][i], cidx[j][i]);
+#pragma unroll 2
+      for (int b = (kSubs == 1 ? 0 : (int)(threadIdx.x & 3)); b < nbox; b += kSubs) {
         const float4 A = sh_box[b * kEnvsPerWave + quad];
-        float key = norm(v3(A.x, A.y, A.z) - s.footc) - keyC;
-        int idx = l * nbox + b;
+        const unsigned long long pk = packed(norm(v3(A.x, A.y, A.z) - s.footc) - keyC, l * nbox + b);
 #pragma unroll
         for (int i = 0; i < kMaxPenQ; i++) {
           if (i >= ncol) continue;
 #pragma unroll
-          for (int j = 0; j < 4; j++) crank[j][i] += ((key < ckey[j][i]) | ((key == ckey[j][i]) & (idx < cidx[j][i]))) ? 1 : 0;   // `|`, `&`: no short-circuit branches
+          for (int j = 0; j < 4; j++) crank[j][i] += pk < cpk[j][i] ? 1 : 0;
         }
       }
 #pragma unroll
       for (int i = 0; i < kMaxPenQ; i++) {
         if (i >= ncol) continue;
 #pragma unroll
-        for (int j = 0; j < 4; j++) crank[j][i] = quad_sum_i(crank[j][i]);
+        for (int j = 0; j < 4; j++) crank[j][i] = quad_sum_i(sub_sum_i(crank[j][i]));
       }
     }
     PG_TICK(s, 14);

@@ -15,7 +15,7 @@ g = torch.Generator(device="cuda").manual_seed(0)
 for k in range(60):
     env.step(torch.tanh(torch.randn(n, 12, device="cuda", generator=g) * 0.6))
     if k >= 50:
-        buf = np.zeros(65536, np.float32); L.pgtt_trace_read(buf.ctypes.data, buf.size)
+        buf = np.zeros(262144, np.float32); L.pgtt_trace_read(buf.ctypes.data, buf.size)
         seg = buf.reshape(4, -1)[(k + 2) % 4]
         t = seg[32:32 + n // 16]; ns = seg[32 + 4096:32 + 4096 + n // 16]
         q = np.percentile(t, [0, 10, 50, 90, 99, 100])
