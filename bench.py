@@ -1,6 +1,6 @@
 """Benchmark of the hot path: env-steps/s of the vectorised Go2 joystick_pgtt step on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096] [--workload level4|flat|level13_dr]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096] [--workload level4|flat|level13_dr|wfc_dr|curriculum]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one control step (4 physics substeps + 13x9 scan + obs + 21 rewards + bookkeeping, with the
@@ -29,6 +29,7 @@ ALGO_BYTES_PER_ENV_STEP_DR = 4216
 ALGO_FLOP_PER_ENV_STEP = 1.6e6          # fp32, dense MJX formulation (the reference's arithmetic)
 PEAK_FP32_TFLOPS = 157.3                # MI355X fp32: matrix peak == vector peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+CURRICULUM = [1, 2, 3, 4, 7, 10, 13]    # the level files the reference ships (terrains/level*.npy), easiest first
 
 
 def main():
@@ -37,9 +38,10 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--workload", default="level4", choices=["level4", "flat", "level13_dr", "wfc_dr"])
+    ap.add_argument("--workload", default="level4", choices=["level4", "flat", "level13_dr", "wfc_dr", "curriculum"])
+    ap.add_argument("--stage", type=int, default=None, help="curriculum workload: index into the level list (default: the rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-steps", type=int, default=40)
+    ap.add_argument("--cpu-sample-steps", type=int, default=100)
     args = ap.parse_args()
 
     import torch
@@ -61,8 +63,10 @@ def main():
     kw, terrain, task, dr = {}, None, "stairs", False
     if args.workload == "flat":
         task = "flat_terrain"
-    elif args.workload == "level4":
-        terrain = np.load(os.path.join(assets, "level4.npy"))
+    elif args.workload in ("level4", "curriculum"):
+        # curriculum (BASELINE configs[4]): GPU r trains on stage r of the reference's level files (terrains/level*.npy)
+        level = "level4" if args.workload == "level4" else "level%d" % CURRICULUM[(rank if args.stage is None else args.stage) % len(CURRICULUM)]
+        terrain = np.load(os.path.join(assets, level + ".npy"))
         variant = np.random.Generator(np.random.Philox(key=[2, 0])).integers(0, terrain.shape[0], n * max(world, 1))[off:off + n]
         kw["variant"] = torch.from_numpy(variant.astype(np.int32))
     else:
@@ -131,6 +135,7 @@ def main():
             "config": {"workload": {"level4": "4096 Go2 envs/GPU, terrains/level4.npy (100 variants x 100 boxes) + 13x9 height scan, no DR (BASELINE configs[2])",
                                     "flat": "4096 Go2 envs/GPU, plane only, no DR (BASELINE configs[1])",
                                     "level13_dr": "Go2 envs/GPU, level13 + full randomize.py DR (BASELINE configs[3] shape)",
+                                    "curriculum": "Go2 envs/GPU, rank r on stage r of terrains/level{1,2,3,4,7,10,13}.npy + height scan, no DR (BASELINE configs[4])",
                                     "wfc_dr": "Go2 envs/GPU, WFC-generated stairs (terrain_gen.py, 100 variants) + full randomize.py DR (BASELINE configs[3])"}[args.workload],
                        "envs_per_gpu": n, "substeps": 4, "autoreset": True, "actions": "tanh(N(0,0.6)) iid", "parallelism": f"env-shard x{world}"},
             "kernels_ms": {"physics_kernel": phys_ms, "observe_kernel": obs_ms, "launches": ntimed},

@@ -188,6 +188,14 @@ def test_level13_dr_autoreset_parity(layout):
     run_parity("stairs", 128, terrain, steps=40, dr=True, autoreset=True)
 
 
+@pytest.mark.parametrize("level", [1, 2, 3, 7, 10])
+def test_curriculum_levels_parity(level):
+    """the remaining level files of the reference's curriculum (BASELINE configs[4]; level4 and level13 are covered above;
+    level2 / level3 hold 50 variants instead of 100) through the same parity bar, default lane layout"""
+    terrain = np.load(os.path.join(ASSETS, "terrains", f"level{level}.npy"))
+    run_parity("stairs", 128, terrain, steps=24)
+
+
 def test_ragged_env_counts_parity(layout):
     """env counts that are not multiples of the 16 envs of a wave (partial last wave, grid not a multiple of the 8
     XCDs, a single partial wave) go through the same parity bar"""
