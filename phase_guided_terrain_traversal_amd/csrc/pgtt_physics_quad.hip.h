@@ -212,19 +212,22 @@ PG_INL void qarrow_mul(const QArrow& A, const float* xb, const float* xl, float*
 }
 PG_INL void qarrow_factor(QArrow& A) {
   float* c = A.ll;
-  float l00 = sqrtf(c[0]);
-  float l10 = c[1] / l00, l20 = c[3] / l00;
-  float l11 = sqrtf(c[2] - l10 * l10);
-  float l21 = (c[4] - l20 * l10) / l11;
-  float l22 = sqrtf(c[5] - l20 * l20 - l21 * l21);
-  c[0] = l00; c[1] = l10; c[2] = l11; c[3] = l20; c[4] = l21; c[5] = l22;
+  // The diagonal of a Cholesky factor is only ever used as a divisor (here and in qarrow_solve), so the factor keeps its
+  // INVERSE: one v_rsq_f32 (1 ulp) per pivot and multiplications instead of a square root plus ~40 divisions (8
+  // instructions each in the 1-ulp form) per factorisation + solve.
+  const float i00 = __builtin_amdgcn_rsqf(c[0]);
+  float l10 = c[1] * i00, l20 = c[3] * i00;
+  const float i11 = __builtin_amdgcn_rsqf(c[2] - l10 * l10);
+  float l21 = (c[4] - l20 * l10) * i11;
+  const float i22 = __builtin_amdgcn_rsqf(c[5] - l20 * l20 - l21 * l21);
+  c[0] = i00; c[1] = l10; c[2] = i11; c[3] = l20; c[4] = l21; c[5] = i22;
   float* w = A.lb;
   if (kSubs == 1) {
 #pragma unroll
     for (int k = 0; k < 6; k++) {
-      float w0 = w[k] / l00;
-      float w1 = (w[6 + k] - l10 * w0) / l11;
-      float w2 = (w[12 + k] - l20 * w0 - l21 * w1) / l22;
+      float w0 = w[k] * i00;
+      float w1 = (w[6 + k] - l10 * w0) * i11;
+      float w2 = (w[12 + k] - l20 * w0 - l21 * w1) * i22;
       w[k] = w0; w[6 + k] = w1; w[12 + k] = w2;
     }
 #pragma unroll
@@ -243,9 +246,9 @@ PG_INL void qarrow_factor(QArrow& A) {
     float ca[3], cb[3];
     {
       const float a0 = pick(w[0], w[1], w[2], w[3]), a1 = pick(w[6], w[7], w[8], w[9]), a2 = pick(w[12], w[13], w[14], w[15]);
-      ca[0] = a0 / l00; ca[1] = (a1 - l10 * ca[0]) / l11; ca[2] = (a2 - l20 * ca[0] - l21 * ca[1]) / l22;
+      ca[0] = a0 * i00; ca[1] = (a1 - l10 * ca[0]) * i11; ca[2] = (a2 - l20 * ca[0] - l21 * ca[1]) * i22;
       const float e0 = b0 ? w[5] : w[4], e1 = b0 ? w[11] : w[10], e2 = b0 ? w[17] : w[16];
-      cb[0] = e0 / l00; cb[1] = (e1 - l10 * cb[0]) / l11; cb[2] = (e2 - l20 * cb[0] - l21 * cb[1]) / l22;
+      cb[0] = e0 * i00; cb[1] = (e1 - l10 * cb[0]) * i11; cb[2] = (e2 - l20 * cb[0] - l21 * cb[1]) * i22;
     }
 #pragma unroll
     for (int m = 0; m < 3; m++) {
@@ -277,43 +280,43 @@ PG_INL void qarrow_factor(QArrow& A) {
     float s = A.bb[tri(j, j)];
 #pragma unroll
     for (int k = 0; k < j; k++) s -= A.bb[tri(j, k)] * A.bb[tri(j, k)];
-    float d = sqrtf(s);
-    A.bb[tri(j, j)] = d;
+    const float id = __builtin_amdgcn_rsqf(s);
+    A.bb[tri(j, j)] = id;
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {
       float t = A.bb[tri(i, j)];
 #pragma unroll
       for (int k = 0; k < j; k++) t -= A.bb[tri(i, k)] * A.bb[tri(j, k)];
-      A.bb[tri(i, j)] = t / d;
+      A.bb[tri(i, j)] = t * id;
     }
   }
 }
 PG_INL void qarrow_solve(const QArrow& F, const float* bb, const float* bl, float* xb, float* xl) {
   const float* c = F.ll;
-  float y0 = bl[0] / c[0];
-  float y1 = (bl[1] - c[1] * y0) / c[2];
-  float y2 = (bl[2] - c[3] * y0 - c[4] * y1) / c[5];
+  float y0 = bl[0] * c[0];                    // c[0], c[2], c[5] and bb[tri(i, i)] hold inverse pivots (qarrow_factor)
+  float y1 = (bl[1] - c[1] * y0) * c[2];
+  float y2 = (bl[2] - c[3] * y0 - c[4] * y1) * c[5];
   float z[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     float rb = bb[i] - quad_sum(F.lb[i] * y0 + F.lb[6 + i] * y1 + F.lb[12 + i] * y2);
 #pragma unroll
     for (int k = 0; k < i; k++) rb -= F.bb[tri(i, k)] * z[k];
-    z[i] = rb / F.bb[tri(i, i)];
+    z[i] = rb * F.bb[tri(i, i)];
   }
 #pragma unroll
   for (int i = 5; i >= 0; i--) {
     float s = z[i];
 #pragma unroll
     for (int k = i + 1; k < 6; k++) s -= F.bb[tri(k, i)] * xb[k];
-    xb[i] = s / F.bb[tri(i, i)];
+    xb[i] = s * F.bb[tri(i, i)];
   }
   float t0 = y0, t1 = y1, t2 = y2;
 #pragma unroll
   for (int k = 0; k < 6; k++) { t0 -= F.lb[k] * xb[k]; t1 -= F.lb[6 + k] * xb[k]; t2 -= F.lb[12 + k] * xb[k]; }
-  float x2 = t2 / c[5];
-  float x1 = (t1 - c[4] * x2) / c[2];
-  float x0 = (t0 - c[1] * x1 - c[3] * x2) / c[0];
+  float x2 = t2 * c[5];
+  float x1 = (t1 - c[4] * x2) * c[2];
+  float x0 = (t0 - c[1] * x1 - c[3] * x2) * c[0];
   xl[0] = x0; xl[1] = x1; xl[2] = x2;
 }
 

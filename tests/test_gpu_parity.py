@@ -102,10 +102,13 @@ def run_parity(task, n, terrain, steps, dr=False, autoreset=False, noise=1.0, me
     assert conv0.mean() > 0.5
     assert (np.abs(g["state"][37:55] - hb["state"][37:55]) / (1 + np.abs(hb["state"][37:55])))[:, conv0].max() < 1e-2
     assert np.abs(g["state"][55:] - hb["state"][55:]).max() < 1e-5
-    assert np.abs(g["obs_priv"] - hb["obs_priv"]).max() < 5e-3
+    # the privileged observation holds the accelerometer and actuator forces of the reset's forward pass: compared where
+    # that solve converged on both sides (same reason as in the step loop below)
+    assert np.abs(g["obs_priv"] - hb["obs_priv"])[conv0].max() < 5e-3
+    assert np.abs(g["obs_state"] - hb["obs_state"]).max() < 5e-3
     assert np.array_equal(g["istate"], hb["istate"])
     assert np.array_equal(g["frame"][abi.F_CONTACT:abi.F_CONTACT + 4], hb["frame"][abi.F_CONTACT:abi.F_CONTACT + 4])
-    assert np.abs(g["first_obs"] - hb["first_obs"]).max() < 5e-3
+    assert np.abs(g["first_obs"] - hb["first_obs"])[conv0].max() < 5e-3            # [N][171 + 215]
     rng = np.random.default_rng(1)
     EG, EF, flag_mismatch, set_mismatch, nactive, nbox_active = [], [], 0, 0, 0, 0
     nviol = {}
