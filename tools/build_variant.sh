@@ -1,6 +1,6 @@
 #!/bin/bash
 # Debug helper: build an alternate libpgtt under alt_build/ with extra compiler flags.
-#   tools/build_variant.sh NAME [extra hipcc flags...]   ->  alt_build/libpgtt_NAME.so   (use with PGTT_LIB=...)
+#   tools/build_variant.sh NAME [extra hipcc flags...]   (the product flags -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp are NOT implied)  ->  alt_build/libpgtt_NAME.so (use with PGTT_LIB=...)
 set +m
 out=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
