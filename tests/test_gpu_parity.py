@@ -191,10 +191,11 @@ def test_level13_dr_autoreset_parity(layout):
     run_parity("stairs", 128, terrain, steps=40, dr=True, autoreset=True)
 
 
-@pytest.mark.parametrize("level", [1, 2, 3, 7, 10])
+@pytest.mark.parametrize("level", ["1", "2", "3", "7", "10", "05", "09"])
 def test_curriculum_levels_parity(level):
-    """the remaining level files of the reference's curriculum (BASELINE configs[4]; level4 and level13 are covered above;
-    level2 / level3 hold 50 variants instead of 100) through the same parity bar, default lane layout"""
+    """the remaining level files of the reference's training curriculum (BASELINE configs[4]; level4 and level13 are covered
+    above; level2 / level3 hold 50 variants instead of 100) and two of its fixed-step-height evaluation series level01..09
+    (training/evaluate_multiple.py:11-12) through the same parity bar, default lane layout"""
     terrain = np.load(os.path.join(ASSETS, "terrains", f"level{level}.npy"))
     run_parity("stairs", 128, terrain, steps=24)
 
