@@ -129,6 +129,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   s.niter = 0; s.niter_max = 0;
   QPhysics ph(m, em, s, l);
   QSolver sol(m, s, slots);
+  sol.lds_slots = HAS_TERRAIN && nbox > 0;
 #ifdef PGTT_TRACE
   if (valid && e == 0 && a.trace && threadIdx.x % kSubs == 0) s.tr = a.trace + l;
 #endif

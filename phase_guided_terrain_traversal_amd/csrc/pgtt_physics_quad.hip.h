@@ -619,6 +619,9 @@ struct QPhysics {
       else { c.row_active = false; c.D = 0.f; c.aref[0] = 0.f; c.aref[1] = 0.f; c.aref[2] = 0.f; c.aref[3] = 0.f; }
     }
     if (!has_boxes) return;
+    // hex layout: box slot 3 is free unless some foot of the wave holds four box contacts; the plane contact then goes
+    // into its record and sub-lane 3 works on it like the other sub-lanes work on their box slots (QSolver::plane_sub)
+    if (kSubs == 4 && __ballot(s.nbox > 3) == 0ull) slots.store(3, s.con0);
     float sr[2], si[5];
     mix(m->foot_solref, m->foot_solimp, m->foot_solmix, m->box_solref, m->box_solimp, m->box_solmix, sr, si);
     float margin = fmaxf(m->foot_margin, m->box_margin) - fmaxf(m->foot_gap, m->box_gap);
@@ -826,15 +829,24 @@ struct QPhysics {
       for (int i = 0; i < kMaxPenQ; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) cpk[j][i] = packed(ckey[j][i], cidx[j][i]);
-#pragma unroll 2
-      for (int b = (kSubs == 1 ? 0 : (int)(threadIdx.x & 3)); b < nbox; b += kSubs) {
-        const float4 A = sh_box[b * kEnvsPerWave + quad];
+      const int b0 = kSubs == 1 ? 0 : (int)(threadIdx.x & 3);
+      float4 An = sh_box[b0 * kEnvsPerWave + quad];
+#pragma unroll 1
+      for (int b = b0; b < nbox; b += kSubs) {
+        const float4 A = An;
+        const int bn = b + kSubs < PGTT_MAX_BOX ? b + kSubs : b;       // next row, read while this one is ranked (rows >= nbox: stale, unused)
+        An = sh_box[bn * kEnvsPerWave + quad];
         const unsigned long long pk = packed(norm(v3(A.x, A.y, A.z) - s.footc) - keyC, l * nbox + b);
 #pragma unroll
         for (int i = 0; i < kMaxPenQ; i++) {
           if (i >= ncol) continue;
 #pragma unroll
-          for (int j = 0; j < 4; j++) crank[j][i] += pk < cpk[j][i] ? 1 : 0;
+          for (int j = 0; j < 4; j++) {
+            // cnt += (pk < cpk) as compare + add-with-carry through VCC: written out because the compiler keeps the 16
+            // compare masks of a box alive in SGPR pairs and spills them through v_writelane (a borrow chain
+            // v_sub_co / v_subb_co / v_addc_co instead of the 64-bit compare measured the same)
+            asm("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(crank[j][i]) : "v"(pk), "v"(cpk[j][i]) : "vcc");
+          }
         }
       }
 #pragma unroll
@@ -905,6 +917,12 @@ struct QSolver {
   int nslots;     // wave-uniform number of own-box-contact slots in use anywhere in the wave
   typedef float f2 __attribute__((ext_vector_type(2)));
   f2 hx_ja, hx_jv, hx_D;    // hex layout: (limit row, plane-contact row) of the own sub-lane for the current line search
+  bool lds_slots = false;   // the kernel has slot records in LDS (box terrain)
+  bool plane_sub = false;   // hex layout, wave-uniform: the plane contact sits in slot 3 and is worked on by sub-lane 3 (its
+                            // Jacobian products, force and Hessian in the same single pass as the box slots of sub-lanes
+                            // 0..2 instead of replicated in all four sub-lanes); its four rows are handed back to jar0 / jv0
+  PG_INL bool own_on(int k) const { return (k < nslots) | (plane_sub & (k == 3)); }
+  PG_INL bool own_any() const { return nslots > 0 || plane_sub; }
   bool any_lim, any_con0;   // wave-uniform: some lane has an active joint-limit row / an active plane contact.
                             // Inactive rows have D = 0 and aref = 0: they add exact zeros, so skipping them is bit-neutral.
   const BoxSlots slots;
@@ -954,20 +972,25 @@ struct QSolver {
     const S6 tw = twist(qb, ql);
 #pragma unroll
     for (int r = 0; r < 4; r++) jar0[r] = 0.f;
-    if (any_con0) {
+    if (any_con0 && !plane_sub) {
       float jx[4];
       con_jx(s.con0, tw, jx);
 #pragma unroll
       for (int r = 0; r < 4; r++) jar0[r] = (s.con0.row_active ? jx[r] : 0.f) - s.con0.aref[r];
     }
-    for (int k0 = 0; k0 < (kSubs == 1 ? nslots : (nslots > 0 ? 1 : 0)); k0++) {
+    float pv[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < (kSubs == 1 ? nslots : (own_any() ? 1 : 0)); k0++) {
       const int k = kSubs == 1 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
-      if (k >= nslots) continue;
+      if (!own_on(k)) continue;
       const QContact cn = slots.load(k);
       float jx[4];
       con_jx(cn, tw, jx);
 #pragma unroll
-      for (int r = 0; r < 4; r++) slots.jar(k, r) = (cn.row_active ? jx[r] : 0.f) - cn.aref[r];
+      for (int r = 0; r < 4; r++) { pv[r] = (cn.row_active ? jx[r] : 0.f) - cn.aref[r]; slots.jar(k, r) = pv[r]; }
+    }
+    if (plane_sub) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) jar0[r] = sub_bcast<3>(pv[r]);
     }
     cost = INFINITY; prev_cost = 0.f;
   }
@@ -998,19 +1021,19 @@ struct QSolver {
       V3 fw = cn.fr[0] * g[0] + cn.fr[1] * g[1] + cn.fr[2] * g[2];
       F.l = F.l + fw; F.a = F.a + cross(cn.off, fw);
     };
-    if (any_con0) add_contact(s.con0, jar0, Fs, csum);
+    if (any_con0 && !plane_sub) add_contact(s.con0, jar0, Fs, csum);
     if (kSubs == 1) {
       for (int k = 0; k < nslots; k++) {
         const QContact cn = slots.load(k);
         float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
         add_contact(cn, ja4, Fs, csum);
       }
-    } else if (nslots > 0) {
+    } else if (own_any()) {
       // hex layout: the owner of a slot forms its force; the sub-lane sum gives every lane the leg's total
       S6 Fd{v3(0, 0, 0), v3(0, 0, 0)}; float cd = 0.f;
-      for (int k0 = 0; k0 < (kSubs == 1 ? nslots : (nslots > 0 ? 1 : 0)); k0++) {
-        const int k = kSubs == 1 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
-        if (k >= nslots) continue;
+      for (int k0 = 0; k0 < 1; k0++) {
+        const int k = (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
+        if (!own_on(k)) continue;
         const QContact cn = slots.load(k);
         float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
         add_contact(cn, ja4, Fd, cd);
@@ -1079,14 +1102,14 @@ struct QSolver {
         for (int j = 0; j <= i; j++) llt[tri(i, j)] += dot(col[6 + i], y[6 + j]);
       }
     };
-    if (any_con0) add_hessian(s.con0, jar0, Gbb, H.lb, H.ll);
+    if (any_con0 && !plane_sub) add_hessian(s.con0, jar0, Gbb, H.lb, H.ll);
     if (kSubs == 1) {
       for (int k = 0; k < nslots; k++) {
         const QContact cn = slots.load(k);
         float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
         add_hessian(cn, ja4, Gbb, H.lb, H.ll);
       }
-    } else if (nslots > 0) {
+    } else if (own_any()) {
       // hex layout: the owner of a slot forms its 45 Hessian entries; the sub-lane sums give every lane the leg's total
       float Gd[21], lbd[18], lld[6];
 #pragma unroll
@@ -1095,9 +1118,9 @@ struct QSolver {
       for (int i = 0; i < 18; i++) lbd[i] = 0.f;
 #pragma unroll
       for (int i = 0; i < 6; i++) lld[i] = 0.f;
-      for (int k0 = 0; k0 < (kSubs == 1 ? nslots : (nslots > 0 ? 1 : 0)); k0++) {
-        const int k = kSubs == 1 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
-        if (k >= nslots) continue;
+      for (int k0 = 0; k0 < 1; k0++) {
+        const int k = (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
+        if (!own_on(k)) continue;
         const QContact cn = slots.load(k);
         float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
         add_hessian(cn, ja4, Gd, lbd, lld);
@@ -1222,20 +1245,25 @@ struct QSolver {
     const S6 tws = twist(sb, sl);
 #pragma unroll
     for (int r = 0; r < 4; r++) jv0[r] = 0.f;
-    if (any_con0) {
+    if (any_con0 && !plane_sub) {
       float jx[4];
       con_jx(s.con0, tws, jx);
 #pragma unroll
       for (int r = 0; r < 4; r++) jv0[r] = s.con0.row_active ? jx[r] : 0.f;
     }
-    for (int k0 = 0; k0 < (kSubs == 1 ? nslots : (nslots > 0 ? 1 : 0)); k0++) {
+    float pv[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < (kSubs == 1 ? nslots : (own_any() ? 1 : 0)); k0++) {
       const int k = kSubs == 1 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
-      if (k >= nslots) continue;
+      if (!own_on(k)) continue;
       const QContact cn = slots.load(k);
       float jx[4];
       con_jx(cn, tws, jx);
 #pragma unroll
-      for (int r = 0; r < 4; r++) slots.jv(k, r) = cn.row_active ? jx[r] : 0.f;
+      for (int r = 0; r < 4; r++) { pv[r] = cn.row_active ? jx[r] : 0.f; slots.jv(k, r) = pv[r]; }
+    }
+    if (plane_sub) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) jv0[r] = sub_bcast<3>(pv[r]);
     }
     if (kSubs == 4) {
       // pick by bit tests (selects, no branches): r = 0..3
@@ -1304,9 +1332,9 @@ struct QSolver {
     for (int k = 0; k < 3; k++) { ql[k] += sl[k] * ia; Mal[k] += mvl[k] * ia; jar_lim[k] += jv_lim[k] * ia; }
 #pragma unroll
     for (int r = 0; r < 4; r++) jar0[r] += jv0[r] * ia;
-    for (int k0 = 0; k0 < (kSubs == 1 ? nslots : (nslots > 0 ? 1 : 0)); k0++) {
+    for (int k0 = 0; k0 < (kSubs == 1 ? nslots : (own_any() ? 1 : 0)); k0++) {
       const int k = kSubs == 1 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
-      if (k >= nslots) continue;
+      if (!own_on(k)) continue;
 #pragma unroll
       for (int r = 0; r < 4; r++) slots.jar(k, r) += slots.jv(k, r) * ia;
     }
@@ -1322,6 +1350,7 @@ struct QSolver {
 #endif
     any_lim = __ballot(s.lim_active[0] || s.lim_active[1] || s.lim_active[2]) != 0ull;
     any_con0 = __ballot(s.con0.row_active) != 0ull;
+    plane_sub = kSubs == 4 && lds_slots && nb <= 3 && any_con0;
     PG_TICK(s, 3);
     // start from the cheaper of (unconstrained acceleration, warm start).  The warm start is evaluated LAST: when it wins
     // in every lane of the wave (the steady state) the solver state is already the one to continue from; only a wave
