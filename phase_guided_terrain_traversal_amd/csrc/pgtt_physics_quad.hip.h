@@ -6,8 +6,8 @@
 // in the lanes of the env and kept bitwise identical: cross-lane sums are symmetric DPP butterflies that return the same
 // bits in every lane.  Two layouts (compile-time PG_SUBS, see "cross-lane primitives" below): quad = one lane per leg,
 // 16 envs per wave; hex = four sub-lanes per leg (leg state replicated, selected loops split), 4 envs per wave.
-// Box-contact records live in LDS (one column per leg); everything else is in registers (96-128 B of scratch in the
-// terrain kernels, none in the flat ones).
+// Box-contact records live in LDS (one column per leg); everything else is in registers (256 VGPRs plus 230-255 AGPRs used
+// as spill space, no scratch).
 //
 // Arithmetic contract: MJX forward + Euler for the Go2 tree, active contact set identical to MJX's top-k semantics,
 // Newton(5) x linesearch(5); see pgtt_physics.hip.h for the shared helpers and DESIGN.md 5.1 for the invariants.
