@@ -921,6 +921,12 @@ struct QSolver {
   bool plane_sub = false;   // hex layout, wave-uniform: the plane contact sits in slot 3 and is worked on by sub-lane 3 (its
                             // Jacobian products, force and Hessian in the same single pass as the box slots of sub-lanes
                             // 0..2 instead of replicated in all four sub-lanes); its four rows are handed back to jar0 / jv0
+  // hex layout: the contact this sub-lane works on (box slot = sub-lane index, or the plane contact) is read from its slot
+  // record ONCE per solve and kept in registers with its four rows (mjar, mjv; mirrored in the record for the sub-lanes
+  // that evaluate them in the line search); the rows r of the box slots that this sub-lane evaluates are read ONCE per
+  // line search (ls_ja / ls_jv / ls_D, slot pairs (0,1) and (2,3)) - the Newton loop otherwise re-read ~100 LDS words per trip
+  QContact mine; float mjar[4], mjv[4];
+  f2 ls_ja[2], ls_jv[2], ls_D[2];
   PG_INL bool own_on(int k) const { return (k < nslots) | (plane_sub & (k == 3)); }
   PG_INL bool own_any() const { return nslots > 0 || plane_sub; }
   bool any_lim, any_con0;   // wave-uniform: some lane has an active joint-limit row / an active plane contact.
@@ -982,11 +988,11 @@ struct QSolver {
     for (int k0 = 0; k0 < (kSubs == 1 ? nslots : (own_any() ? 1 : 0)); k0++) {
       const int k = kSubs == 1 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
       if (!own_on(k)) continue;
-      const QContact cn = slots.load(k);
+      const QContact cn = kSubs == 1 ? slots.load(k) : mine;
       float jx[4];
       con_jx(cn, tw, jx);
 #pragma unroll
-      for (int r = 0; r < 4; r++) { pv[r] = (cn.row_active ? jx[r] : 0.f) - cn.aref[r]; slots.jar(k, r) = pv[r]; }
+      for (int r = 0; r < 4; r++) { pv[r] = (cn.row_active ? jx[r] : 0.f) - cn.aref[r]; slots.jar(k, r) = pv[r]; if (kSubs == 4) mjar[r] = pv[r]; }
     }
     if (plane_sub) {
 #pragma unroll
@@ -1034,9 +1040,7 @@ struct QSolver {
       for (int k0 = 0; k0 < 1; k0++) {
         const int k = (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
         if (!own_on(k)) continue;
-        const QContact cn = slots.load(k);
-        float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
-        add_contact(cn, ja4, Fd, cd);
+        add_contact(mine, mjar, Fd, cd);
       }
       Fs.l = Fs.l + v3(sub_sum(Fd.l.x), sub_sum(Fd.l.y), sub_sum(Fd.l.z));
       Fs.a = Fs.a + v3(sub_sum(Fd.a.x), sub_sum(Fd.a.y), sub_sum(Fd.a.z));
@@ -1121,9 +1125,7 @@ struct QSolver {
       for (int k0 = 0; k0 < 1; k0++) {
         const int k = (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
         if (!own_on(k)) continue;
-        const QContact cn = slots.load(k);
-        float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
-        add_hessian(cn, ja4, Gd, lbd, lld);
+        add_hessian(mine, mjar, Gd, lbd, lld);
       }
 #pragma unroll
       for (int i = 0; i < 21; i++) Gbb[i] += sub_sum(Gd[i]);
@@ -1196,13 +1198,8 @@ struct QSolver {
       // plane contact and of each box slot); the sums below run over all 16 lanes of the env
       const int r = threadIdx.x & 3;
       if (any_lim || any_con0) ls_row2d<NA>(hx_ja, hx_jv, hx_D, al, q);       // own (limit row, plane row), picked once per search
-      for (int k = 0; k < nslots; k += 2) {
-        const bool two = k + 1 < nslots;
-        const int k1 = two ? k + 1 : k;
-        const f2 ja{slots.jar(k, r), two ? slots.jar(k1, r) : 0.f}, jv{slots.jv(k, r), two ? slots.jv(k1, r) : 0.f};
-        const f2 D{slots.at(k, 2), two ? slots.at(k1, 2) : 0.f};
-        ls_row2d<NA>(ja, jv, D, al, q);
-      }
+      if (nslots > 0) ls_row2d<NA>(ls_ja[0], ls_jv[0], ls_D[0], al, q);
+      if (nslots > 2) ls_row2d<NA>(ls_ja[1], ls_jv[1], ls_D[1], al, q);
     }
 #pragma unroll
     for (int a = 0; a < NA; a++) {
@@ -1255,11 +1252,11 @@ struct QSolver {
     for (int k0 = 0; k0 < (kSubs == 1 ? nslots : (own_any() ? 1 : 0)); k0++) {
       const int k = kSubs == 1 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
       if (!own_on(k)) continue;
-      const QContact cn = slots.load(k);
+      const QContact cn = kSubs == 1 ? slots.load(k) : mine;
       float jx[4];
       con_jx(cn, tws, jx);
 #pragma unroll
-      for (int r = 0; r < 4; r++) { pv[r] = cn.row_active ? jx[r] : 0.f; slots.jv(k, r) = pv[r]; }
+      for (int r = 0; r < 4; r++) { pv[r] = cn.row_active ? jx[r] : 0.f; slots.jv(k, r) = pv[r]; if (kSubs == 4) mjv[r] = pv[r]; }
     }
     if (plane_sub) {
 #pragma unroll
@@ -1273,6 +1270,15 @@ struct QSolver {
       hx_ja = f2{pick(jar_lim[0], jar_lim[1], jar_lim[2], 0.f), pick(jar0[0], jar0[1], jar0[2], jar0[3])};
       hx_jv = f2{pick(jv_lim[0], jv_lim[1], jv_lim[2], 0.f), pick(jv0[0], jv0[1], jv0[2], jv0[3])};
       hx_D = f2{pick(s.lim_D[0], s.lim_D[1], s.lim_D[2], 0.f), s.con0.D};
+      // rows r of the box slots (written by the sub-lanes that own the slots, just above and in the last epilogue)
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+        const int k = 2 * p, k1 = 2 * p + 1;
+        const bool on0 = k < nslots, on1 = k1 < nslots;           // wave-uniform
+        ls_ja[p] = f2{on0 ? slots.jar(k, r) : 0.f, on1 ? slots.jar(k1, r) : 0.f};
+        ls_jv[p] = f2{on0 ? slots.jv(k, r) : 0.f, on1 ? slots.jv(k1, r) : 0.f};
+        ls_D[p] = f2{on0 ? slots.at(k, 2) : 0.f, on1 ? slots.at(k1, 2) : 0.f};
+      }
     }
     float ab = 0.f, bb_ = 0.f, eb = 0.f, al = 0.f, bl = 0.f, el = 0.f;
 #pragma unroll
@@ -1336,7 +1342,10 @@ struct QSolver {
       const int k = kSubs == 1 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
       if (!own_on(k)) continue;
 #pragma unroll
-      for (int r = 0; r < 4; r++) slots.jar(k, r) += slots.jv(k, r) * ia;
+      for (int r = 0; r < 4; r++) {
+        if (kSubs == 1) slots.jar(k, r) += slots.jv(k, r) * ia;
+        else { mjar[r] += mjv[r] * ia; slots.jar(k, r) = mjar[r]; }
+      }
     }
   }
 
@@ -1351,6 +1360,7 @@ struct QSolver {
     any_lim = __ballot(s.lim_active[0] || s.lim_active[1] || s.lim_active[2]) != 0ull;
     any_con0 = __ballot(s.con0.row_active) != 0ull;
     plane_sub = kSubs == 4 && lds_slots && nb <= 3 && any_con0;
+    if (kSubs == 4 && lds_slots) mine = slots.load((int)(threadIdx.x & 3));
     PG_TICK(s, 3);
     // start from the cheaper of (unconstrained acceleration, warm start).  The warm start is evaluated LAST: when it wins
     // in every lane of the wave (the steady state) the solver state is already the one to continue from; only a wave
