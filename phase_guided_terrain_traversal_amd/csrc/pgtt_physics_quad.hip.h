@@ -795,6 +795,7 @@ struct QPhysics {
 #pragma unroll
     for (int i = 0; i < kMaxPenQ; i++) if (__ballot(npen > i) != 0ull) ncol = i + 1;
     bool need_exact = false;
+    unsigned nearmask = 0u;
     if (broad) {
       // pass 2a: cheap conservative test.  rank(p) < #pairs with key <= max candidate key; if that count (over the
       // 400 pairs, quad-summed) is <= max_geom_pairs, every candidate survives MJX's top-k and the exact ranks are
@@ -805,11 +806,14 @@ struct QPhysics {
       kmax = fmaxf(fmaxf(quad_bcast<0>(kmax), quad_bcast<1>(kmax)), fmaxf(quad_bcast<2>(kmax), quad_bcast<3>(kmax)));
       const float thr = (kmax + keyC) * 1.000002f + 1e-7f, thr2 = kmax > -1.0e38f ? thr * thr : -1.f;
       int cnt = 0;
+      static_assert(PGTT_MAX_BOX <= 128, "hex layout: the <= 32 boxes of a sub-lane are one mask word");
 #pragma unroll 4
-      for (int b = (kSubs == 1 ? 0 : (int)(threadIdx.x & 3)); b < nbox; b += kSubs) {     // hex: boxes go round the sub-lanes
+      for (int t = 0, b = (kSubs == 1 ? 0 : (int)(threadIdx.x & 3)); b < nbox; t++, b += kSubs) {     // hex: boxes go round the sub-lanes
         const float4 A = sh_box[b * kEnvsPerWave + quad];
         V3 dv = v3(A.x, A.y, A.z) - s.footc;
-        cnt += dot(dv, dv) <= thr2 ? 1 : 0;
+        const bool in = dot(dv, dv) <= thr2;
+        cnt += in ? 1 : 0;
+        if (kSubs == 4) nearmask |= (in ? 1u : 0u) << t;     // own boxes that can sort before a candidate (pass 2b)
       }
       need_exact = quad_sum_i(sub_sum_i(cnt)) > maxp;
     }
@@ -829,14 +833,7 @@ struct QPhysics {
       for (int i = 0; i < kMaxPenQ; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) cpk[j][i] = packed(ckey[j][i], cidx[j][i]);
-      const int b0 = kSubs == 1 ? 0 : (int)(threadIdx.x & 3);
-      float4 An = sh_box[b0 * kEnvsPerWave + quad];
-#pragma unroll 1
-      for (int b = b0; b < nbox; b += kSubs) {
-        const float4 A = An;
-        const int bn = b + kSubs < PGTT_MAX_BOX ? b + kSubs : b;       // next row, read while this one is ranked (rows >= nbox: stale, unused)
-        An = sh_box[bn * kEnvsPerWave + quad];
-        const unsigned long long pk = packed(norm(v3(A.x, A.y, A.z) - s.footc) - keyC, l * nbox + b);
+      auto rank_against = [&](unsigned long long pk) {
 #pragma unroll
         for (int i = 0; i < kMaxPenQ; i++) {
           if (i >= ncol) continue;
@@ -847,6 +844,31 @@ struct QPhysics {
             // v_sub_co / v_subb_co / v_addc_co instead of the 64-bit compare measured the same)
             asm("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(crank[j][i]) : "v"(pk), "v"(cpk[j][i]) : "vcc");
           }
+        }
+      };
+      if (kSubs == 1) {
+        float4 An = sh_box[quad];
+#pragma unroll 1
+        for (int b = 0; b < nbox; b++) {
+          const float4 A = An;
+          const int bn = b + 1 < PGTT_MAX_BOX ? b + 1 : b;       // next row, read while this one is ranked (rows >= nbox: stale, unused)
+          An = sh_box[bn * kEnvsPerWave + quad];
+          rank_against(packed(norm(v3(A.x, A.y, A.z) - s.footc) - keyC, l * nbox + b));
+        }
+      } else {
+        // hex layout: only the own boxes that pass 2a found at least as close as the farthest candidate can sort before a
+        // candidate (nearmask, a superset: 2-4 of a sub-lane's 25 boxes); every lane pops its own, the loop ends by ballot
+        unsigned mk = nearmask;
+#pragma unroll 1
+        for (;;) {
+          if (__ballot(mk != 0u) == 0ull) break;
+          const bool have = mk != 0u;
+          const int t = have ? __ffs(mk) - 1 : 0;
+          mk &= mk - 1u;                                            // 0 stays 0
+          const int b = (int)(threadIdx.x & 3) + 4 * t;
+          const float4 A = sh_box[b * kEnvsPerWave + quad];
+          const unsigned long long pk = packed(norm(v3(A.x, A.y, A.z) - s.footc) - keyC, l * nbox + b);
+          rank_against(have ? pk : ~0ull);                          // ~0 sorts after every candidate
         }
       }
 #pragma unroll
