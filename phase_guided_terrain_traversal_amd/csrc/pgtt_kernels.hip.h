@@ -518,11 +518,13 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
   if (HAS_TERRAIN) {
     const int v = a.buf.variant ? a.buf.variant[e] : 0;
     const TerrainBox* __restrict__ boxes = a.terrain + (long)v * a.B;
-    const float rf = sqrtf((0.5f * (PGTT_SCAN_H - 1) * cfg->scan_dist_x) * (0.5f * (PGTT_SCAN_H - 1) * cfg->scan_dist_x) +
-                           (0.5f * (PGTT_SCAN_W - 1) * cfg->scan_dist_y) * (0.5f * (PGTT_SCAN_W - 1) * cfg->scan_dist_y)) + 1e-3f;
-    // cull, lane-parallel: lane j looks at boxes j and j + 64 (world AABB of the box vs the circle around the scan
-    // footprint); the ballots give the boxes worth a ray test, which are then visited with wave-uniform loads.
-    // min() over the hits does not depend on the visiting order.
+    // cull, lane-parallel: lane j looks at boxes j and j + 64: world AABB of the box against the scan footprint, a
+    // rectangle of half-sides (hx, hy) turned by the yaw - the four separating axes of a rectangle / AABB pair in the
+    // plane, with 1 mm of slack (a vertical ray can only hit a box whose footprint contains it, so dropping the boxes
+    // that do not overlap the rectangle changes no hit).  The ballots give the boxes worth a ray test, which are then
+    // visited with wave-uniform loads; min() over the hits does not depend on the visiting order.
+    const float hx = 0.5f * (PGTT_SCAN_H - 1) * fabsf(cfg->scan_dist_x) + 1e-3f, hy = 0.5f * (PGTT_SCAN_W - 1) * fabsf(cfg->scan_dist_y) + 1e-3f;
+    const float acy = fabsf(cy), asy = fabsf(sy);
     unsigned long long todo[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -531,7 +533,9 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
       if (b < a.B) {
         const float4 A = reinterpret_cast<const float4*>(boxes + b)[0];
         const float4 H = reinterpret_cast<const float4*>(boxes + b)[4];
-        reach = fabsf(A.x - bx) <= H.x + rf && fabsf(A.y - by) <= H.y + rf;
+        const float dx = A.x - bx, dy = A.y - by;
+        reach = (fabsf(dx) <= H.x + hx * acy + hy * asy) & (fabsf(dy) <= H.y + hx * asy + hy * acy) &
+                (fabsf(dx * cy + dy * sy) <= hx + H.x * acy + H.y * asy) & (fabsf(dy * cy - dx * sy) <= hy + H.x * asy + H.y * acy);
       }
       todo[h] = __ballot(reach);
     }
