@@ -330,8 +330,15 @@ PG_INL float wave_min(float v) {
   return v;
 }
 
-// vertical ray (0,0,-1) from world point p against one terrain box; generic mjx _ray_box in the box frame
-PG_INL float ray_box_down(const TerrainBox& tb, V3 p) {
+// vertical ray (0,0,-1) from world point p against one terrain box; generic mjx _ray_box in the box frame.  The ray
+// direction in the box frame lv = -R[2][:] is the same for every ray of a box: its reciprocals are formed once per box
+// (v_rcp_f32, 1 ulp) and the six face parameters are (side - lp) * (1 / lv) instead of six divisions per ray; an
+// axis-parallel component gives 1 / (+-0) = +-inf and the same +-inf / NaN face parameters as the division.
+struct RayBox { float il[3]; };
+PG_INL RayBox ray_box_prepare(const TerrainBox& tb) {
+  return RayBox{{__builtin_amdgcn_rcpf(-tb.m20), __builtin_amdgcn_rcpf(-tb.m21), __builtin_amdgcn_rcpf(-tb.m22)}};
+}
+PG_INL float ray_box_down(const TerrainBox& tb, const RayBox& rb, V3 p) {
   V3 rel = p - v3(tb.px, tb.py, tb.pz);
   float lp[3] = {tb.m00 * rel.x + tb.m10 * rel.y + tb.m20 * rel.z, tb.m01 * rel.x + tb.m11 * rel.y + tb.m21 * rel.z,
                  tb.m02 * rel.x + tb.m12 * rel.y + tb.m22 * rel.z};
@@ -342,7 +349,7 @@ PG_INL float ray_box_down(const TerrainBox& tb, V3 p) {
   for (int f = 0; f < 6; f++) {
     const int ax = f % 3, i0 = ax == 0 ? 1 : 0, i1 = ax == 2 ? 1 : 2;
     float side = f < 3 ? sz[ax] : -sz[ax];
-    float x = (side - lp[ax]) / lv[ax];
+    float x = (side - lp[ax]) * rb.il[ax];
     float p0 = lp[i0] + x * lv[i0], p1 = lp[i1] + x * lv[i1];
     const bool valid = (fabsf(p0) <= sz[i0]) & (fabsf(p1) <= sz[i1]) & (x >= 0.f);     // `&`: selects, not branches
     best = (valid & (x < best)) ? x : best;
@@ -546,8 +553,9 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
         const int b = 64 * h + __builtin_ctzll(mk);
         mk &= mk - 1ull;
         TerrainBox tb = boxes[b];
+        const RayBox rb = ray_box_prepare(tb);
 #pragma unroll
-        for (int k = 0; k < 2; k++) hit[k] = fminf(hit[k], ray_box_down(tb, org[k]));
+        for (int k = 0; k < 2; k++) hit[k] = fminf(hit[k], ray_box_down(tb, rb, org[k]));
       }
     }
   }
