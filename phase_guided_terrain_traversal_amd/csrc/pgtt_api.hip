@@ -111,9 +111,10 @@ void launch_physics(pgtt_env* h, const pgtt::KArgs& a_in, const float* action, h
        {{pgtt_launch_physics_s1_1_0_0, pgtt_launch_physics_s1_1_0_1}, {pgtt_launch_physics_s1_1_1_0, pgtt_launch_physics_s1_1_1_1}}},
       {{{pgtt_launch_physics_s4_0_0_0, pgtt_launch_physics_s4_0_0_1}, {pgtt_launch_physics_s4_0_1_0, pgtt_launch_physics_s4_0_1_1}},
        {{pgtt_launch_physics_s4_1_0_0, pgtt_launch_physics_s4_1_0_1}, {pgtt_launch_physics_s4_1_1_0, pgtt_launch_physics_s4_1_1_1}}}};
-  // auto: the hex layout has the shorter instruction stream on box terrain (line-search rows and collision passes are
-  // split over the sub-lanes) but four times the waves; it wins while those still run concurrently (<= 1024 waves)
-  const bool hex = h->layout == 4 || (h->layout == 0 && terr && h->N <= 4096);
+  // auto: the hex layout has the shorter instruction stream (line-search rows, Cholesky columns and - on box terrain - the
+  // collision passes and contact slots are split over the sub-lanes) but four times the waves; it wins while those still
+  // run concurrently, one per SIMD (<= 1024 waves): level4 0.21 ms against 0.39 ms, flat ground 0.137 ms against 0.141 ms
+  const bool hex = h->layout == 4 || (h->layout == 0 && h->N <= 4096);
   const int per = hex ? 4 : 16;
   table[hex ? 1 : 0][MODE][dr ? 1 : 0][terr ? 1 : 0]((h->N + per - 1) / per, st, a, action);
 }
