@@ -1114,16 +1114,21 @@ struct QSolver {
       col[0] = v3(1, 0, 0); col[1] = v3(0, 1, 0); col[2] = v3(0, 0, 1);
 #pragma unroll
       for (int k = 0; k < 3; k++) { col[3 + k] = s.cdr[k].l + cross(s.cdr[k].a, cn.off); col[6 + k] = s.cdl[k].l + cross(s.cdl[k].a, cn.off); }
+      // The first three columns are the identity: y[0..2] are the columns of A, an entry G[i][j] with j < 3 is component
+      // j of y[i] (A is symmetric; same products in the same order as dot(col[i], y[j])) - 24 of the 45 entries cost no
+      // arithmetic (the compiler may not drop the 0 * x terms of the generic dot products by itself)
+      y[0] = Ax; y[1] = Ay; y[2] = Az;
 #pragma unroll
-      for (int k = 0; k < 9; k++) y[k] = v3(dot(Ax, col[k]), dot(Ay, col[k]), dot(Az, col[k]));
+      for (int k = 3; k < 9; k++) y[k] = v3(dot(Ax, col[k]), dot(Ay, col[k]), dot(Az, col[k]));
+      auto comp = [](V3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); };
 #pragma unroll
       for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = 0; j <= i; j++) Gt[tri(i, j)] += dot(col[i], y[j]);
+        for (int j = 0; j <= i; j++) Gt[tri(i, j)] += j < 3 ? comp(y[i], j) : dot(col[i], y[j]);
 #pragma unroll
       for (int i = 0; i < 3; i++) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) lbt[i * 6 + k] += dot(col[6 + i], y[k]);
+        for (int k = 0; k < 6; k++) lbt[i * 6 + k] += k < 3 ? comp(y[6 + i], k) : dot(col[6 + i], y[k]);
 #pragma unroll
         for (int j = 0; j <= i; j++) llt[tri(i, j)] += dot(col[6 + i], y[6 + j]);
       }
