@@ -84,3 +84,13 @@ def test_model_struct_roundtrip():
     assert c.n_substeps == 4 and abs(c.cmd_u_max[2] - 1.0) < 1e-7 and abs(c.gait_freq[1] - 3) < 1e-7
     assert abs(c.reward_scale[abi.REWARD_KEYS.index("feet_phase")] - 0.5) < 1e-7
     assert abs(c.reward_scale[abi.REWARD_KEYS.index("contact")] - 2.0) < 1e-7
+
+
+def test_tools_and_entry_points_compile():
+    """the GPU-side helper scripts cannot run here; at least they must be syntactically valid"""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, "tools", "*.py")) + [os.path.join(root, f) for f in ("bench.py", "train.py", "__graft_entry__.py")]
+    assert len(files) > 10
+    for f in files:
+        compile(open(f).read(), f, "exec")
