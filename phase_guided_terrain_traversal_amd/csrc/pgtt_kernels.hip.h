@@ -472,9 +472,19 @@ PG_INL void task_rewards(const float* sh_st, const float* sh_fr, const float* sh
     metrics[PGTT_NREW] = sp / 4;
 }
 
+#ifdef PGTT_TIME
+// -DPGTT_TIME=<env> builds (tools/gpu_observe_time.py): phase ticks of the observe wave of that env at a.trace[60000 + i]
+#define PG_OTICK(i) do { if (OMODE == OBS_STEP && e == PGTT_TIME && a.trace) { long long t_ = __builtin_readcyclecounter(); if (lane == 0) a.trace[60000 + (i)] = (float)(t_ - ot0_); } } while (0)
+#else
+#define PG_OTICK(i) ((void)0)
+#endif
 template <int OMODE, bool HAS_TERRAIN>
 __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __restrict__ action) {
   const int e = xcd_block(blockIdx.x, gridDim.x), lane = threadIdx.x, N = a.N;
+#ifdef PGTT_TIME
+  const long long ot0_ = __builtin_readcyclecounter();
+  const unsigned ow0_ = (unsigned)wall_clock64();
+#endif
   if (OMODE != OBS_STEP && OMODE != OBS_STEP_OBS && a.mask && !a.mask[e]) return;
   const PgttModel* __restrict__ m = a.model;
   const PgttConfig* __restrict__ cfg = a.cfg;
@@ -491,6 +501,7 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
   for (int r = lane; r < PGTT_NFRAME; r += 64) sh_fr[r] = a.buf.frame[r * (long)N + e];
   if (OMODE == OBS_STEP && lane < 12) sh_act[lane] = action[(long)e * 12 + lane];
   __syncthreads();
+  PG_OTICK(0);
 
   // ---------------- height scan (heightmap.py:25-67)
   const float bx = sh_st[PGTT_S_QPOS + 0], by = sh_st[PGTT_S_QPOS + 1], bz = sh_st[PGTT_S_QPOS + 2];
@@ -559,6 +570,7 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
       }
     }
   }
+  PG_OTICK(1);
   float z[2];
 #pragma unroll
   for (int h = 0; h < 2; h++) {
@@ -594,6 +606,7 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
   }
   const float zmin = wave_min(fminf(z[0], v1 ? z[1] : INFINITY));
 
+  PG_OTICK(2);
   // ---------------- per-env scalars (computed redundantly by every lane from LDS)
   // method 1 = the baseline task go2/joystick.py: no phase / gait_freq rows in the observation (162 / 206 instead of
   // 171 / 215), H_max = quadrant max, world-frame clearance target, 0.5 s air-time threshold
@@ -643,6 +656,7 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
     }
   }
 
+  PG_OTICK(3);
   // ---------------- observation rows in LDS (joystick_pgtt.py:336-365)
   const float lvl = cfg->noise_level;
   for (int io = lane; io < OBSD; io += 64) {
@@ -701,6 +715,7 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
     return;
   }
 
+  PG_OTICK(4);
   // ---------------- rewards, termination, bookkeeping
   float reward = 0.f; bool done = false; float metrics[PGTT_NMETRIC];
 #pragma unroll
@@ -723,6 +738,7 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
     for (int k = 0; k < PGTT_NMETRIC; k++) metrics[k] = t.metrics[k];
     if (lane < 12) act_i = sh_act[lane];
   }
+  PG_OTICK(5);
   // ---------------- Episode / AutoReset wrapper semantics (UPSTREAM-RECALL)
   bool wdone = done;
   if (OMODE == OBS_STEP && cfg->autoreset) {
@@ -740,6 +756,7 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
     }
   }
 
+  PG_OTICK(6);
   // ---------------- stores
   if (lane < 3) S[(PGTT_S_CMD + lane) * (long)N + e] = sel4(lane, cmd[0], cmd[1], cmd[2], 0.f);
   if (lane < 4) {
@@ -782,6 +799,13 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
     for (int i = lane; i < OBSD; i += 64) a.buf.obs_state[(long)e * OBSD + i] = sh_obs[i];
     for (int i = lane; i < PRIVD; i += 64) a.buf.obs_priv[(long)e * PRIVD + i] = sh_obs[OBSD + i];
   }
+  PG_OTICK(7);
+#ifdef PGTT_TIME
+  if (OMODE == OBS_STEP && a.trace && lane == 0 && blockIdx.x < 4096) {      // placement and timeline of every observe wave
+    unsigned* tw = (unsigned*)(a.trace + 40960 + 4 * blockIdx.x);
+    tw[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4); tw[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20); tw[2] = ow0_; tw[3] = (unsigned)wall_clock64();
+  }
+#endif
   if (OMODE == OBS_RESET) {
     if (a.buf.first_state) for (int r = lane; r < PGTT_S_CMD; r += 64) a.buf.first_state[r * (long)N + e] = sh_st[r];
     if (a.buf.first_obs) for (int i = lane; i < OBSD + PRIVD; i += 64) a.buf.first_obs[(long)e * (OBSD + PRIVD) + i] = sh_obs[i];
