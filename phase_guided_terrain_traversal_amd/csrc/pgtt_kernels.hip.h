@@ -375,6 +375,23 @@ struct TaskScalars {
   float phase_dt; int step_ctr, timer;
   bool done; float reward; float metrics[PGTT_NMETRIC];
 };
+// sums over the 16 lanes of a DPP row / the 4 lanes of a quad, the same bits in every lane (symmetric butterflies, plain adds)
+PG_INL float row16_sum(float x) {
+#pragma clang fp contract(off)
+  x = x + dpp_f<0xB1>(x); x = x + dpp_f<0x4E>(x); x = x + dpp_f<0x128>(x); x = x + dpp_f<0x124>(x);
+  return x;
+}
+PG_INL float quad4_sum(float x) {
+#pragma clang fp contract(off)
+  x = x + dpp_f<0xB1>(x); x = x + dpp_f<0x4E>(x);
+  return x;
+}
+PG_INL float quad4_min(float x) { x = fminf(x, dpp_f<0xB1>(x)); x = fminf(x, dpp_f<0x4E>(x)); return x; }
+// WAVE = true (fused observe kernel, one env per wave, every lane holds the same per-env scalars): the 12 joint terms and the
+// 4 foot terms are evaluated by the lanes of a row / a quad in parallel (lane & 15 = joint, lane & 3 = foot) and summed
+// with DPP butterflies - a fraction of the instructions of the serial loops and of the ~130 VGPRs their unrolled bodies keep
+// alive.  WAVE = false (task_kernel, one env per lane): the serial loops.
+template <bool WAVE>
 PG_INL void task_rewards(const float* sh_st, const float* sh_fr, const float* sh_act, const PgttConfig* __restrict__ cfg,
                          const PgttModel* __restrict__ m, bool baseline, unsigned long long seed, unsigned id, unsigned ep, float dt,
                          TaskScalars& t) {
@@ -397,17 +414,24 @@ PG_INL void task_rewards(const float* sh_st, const float* sh_fr, const float* sh
     rew[PGTT_R_ORIENTATION] = sh_fr[PGTT_F_UPVECTOR] * sh_fr[PGTT_F_UPVECTOR] + sh_fr[PGTT_F_UPVECTOR + 1] * sh_fr[PGTT_F_UPVECTOR + 1];
     {
       float sa = 0.f, lim = 0.f, pose = 0.f, s2 = 0.f, s1 = 0.f, en = 0.f, ar = 0.f;
-#pragma unroll
-      for (int i = 0; i < 12; i++) {
+      auto joint = [&](int i, float on) {
         float q = sh_st[PGTT_S_QPOS + 7 + i], dq = q - m->key_qpos[7 + i];
-        sa += fabsf(dq);
-        pose += (dq * dq) * ((i % 3) == 0 ? 1.0f : 0.1f);
+        sa += on * fabsf(dq);
+        pose += on * ((dq * dq) * ((i % 3) == 0 ? 1.0f : 0.1f));
         float lo = m->jnt_range[i][0] * cfg->soft_joint_pos_limit_factor, hi = m->jnt_range[i][1] * cfg->soft_joint_pos_limit_factor;
-        lim += -fminf(q - lo, 0.f) + fmaxf(q - hi, 0.f);
+        lim += on * (-fminf(q - lo, 0.f) + fmaxf(q - hi, 0.f));
         float f = sh_fr[PGTT_F_ACT_FORCE + i];
-        s2 += f * f; s1 += fabsf(f);
-        en += fabsf(sh_st[PGTT_S_QVEL + 6 + i]) * fabsf(f);
-        float da = sh_act[i] - sh_st[PGTT_S_LAST_ACT + i]; ar += da * da;
+        s2 += on * (f * f); s1 += on * fabsf(f);
+        en += on * (fabsf(sh_st[PGTT_S_QVEL + 6 + i]) * fabsf(f));
+        float da = sh_act[i] - sh_st[PGTT_S_LAST_ACT + i]; ar += on * (da * da);
+      };
+      if constexpr (WAVE) {
+        const int j = (int)(threadIdx.x & 15);
+        joint(j < 12 ? j : 0, j < 12 ? 1.0f : 0.0f);
+        sa = row16_sum(sa); lim = row16_sum(lim); pose = row16_sum(pose); s2 = row16_sum(s2); s1 = row16_sum(s1); en = row16_sum(en); ar = row16_sum(ar);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 12; i++) joint(i, 1.0f);
       }
       rew[PGTT_R_STAND_STILL] = sa * (cmd_norm < 0.01f ? 1.f : 0.f);
       rew[PGTT_R_POSE] = pose; rew[PGTT_R_DOF_POS_LIMITS] = lim;
@@ -416,25 +440,35 @@ PG_INL void task_rewards(const float* sh_st, const float* sh_fr, const float* sh
     rew[PGTT_R_TERMINATION] = done ? 1.f : 0.f;
     {
       float slip = 0.f, clear = 0.f, perr = 0.f, swing = 0.f, airr = 0.f, con = 0.f, center = 0.f, fh = 0.f, minfoot = INFINITY;
-#pragma unroll
-      for (int f = 0; f < 4; f++) {
+      auto foot = [&](int f, float contact_f, float hmax_f, float phase_f, float air_f, float first_f, float peak_f) {
         float vx = sh_fr[PGTT_F_FEET_VEL + 3 * f], vy = sh_fr[PGTT_F_FEET_VEL + 3 * f + 1];
         float v2 = vx * vx + vy * vy;
-        slip += v2 * contact[f];
+        slip += v2 * contact_f;
         float px = sh_fr[PGTT_F_FEET_POS + 3 * f], py = sh_fr[PGTT_F_FEET_POS + 3 * f + 1], pz = sh_fr[PGTT_F_FEET_POS + 3 * f + 2];
-        const float clr = baseline ? sh_fr[PGTT_F_FOOT_SITE_Z + f] - (hmax[f] - cfg->base_feet_distance + cfg->swing_height)   // joystick.py:569-572
-                                   : pz - (hmax[f] + cfg->swing_height);                                                  // joystick_pgtt.py:576-578
+        const float clr = baseline ? sh_fr[PGTT_F_FOOT_SITE_Z + f] - (hmax_f - cfg->base_feet_distance + cfg->swing_height)   // joystick.py:569-572
+                                   : pz - (hmax_f + cfg->swing_height);                                                  // joystick_pgtt.py:576-578
         clear += fabsf(clr) * sqrtf(sqrtf(v2));
-        float rz = gait_get_z(phase[f], hmax[f] + cfg->swing_height, cfg->base_feet_distance);
+        float rz = gait_get_z(phase_f, hmax_f + cfg->swing_height, cfg->base_feet_distance);
         perr += (pz - rz) * (pz - rz);
-        bool swing_mask = phase[f] / (float)(2 * M_PI) >= 0.5f;
+        bool swing_mask = phase_f / (float)(2 * M_PI) >= 0.5f;
         swing += ((pz - cfg->swing_height) * (pz - cfg->swing_height)) * (swing_mask ? 1.f : 0.f);
-        con += (swing_mask && contact[f] != 0.f) ? 1.f : 0.f;
-        airr += (air[f] - (baseline ? 0.5f : 0.1f)) * first_contact[f];        // joystick.py:591 / joystick_pgtt.py:597
+        con += (swing_mask && contact_f != 0.f) ? 1.f : 0.f;
+        airr += (air_f - (baseline ? 0.5f : 0.1f)) * first_f;        // joystick.py:591 / joystick_pgtt.py:597
         center += px * px + py * py;
-        float er = peak[f] / cfg->swing_height - 1.0f;
-        fh += (er * er) * first_contact[f];
+        float er = peak_f / cfg->swing_height - 1.0f;
+        fh += (er * er) * first_f;
         minfoot = fminf(minfoot, sh_fr[PGTT_F_FOOT_SITE_Z + f]);
+      };
+      if constexpr (WAVE) {
+        const int f = (int)(threadIdx.x & 3);
+        foot(f, sel4(f, contact[0], contact[1], contact[2], contact[3]), sel4(f, hmax[0], hmax[1], hmax[2], hmax[3]),
+             sel4(f, phase[0], phase[1], phase[2], phase[3]), sel4(f, air[0], air[1], air[2], air[3]),
+             sel4(f, first_contact[0], first_contact[1], first_contact[2], first_contact[3]), sel4(f, peak[0], peak[1], peak[2], peak[3]));
+        slip = quad4_sum(slip); clear = quad4_sum(clear); perr = quad4_sum(perr); swing = quad4_sum(swing); airr = quad4_sum(airr);
+        con = quad4_sum(con); center = quad4_sum(center); fh = quad4_sum(fh); minfoot = quad4_min(minfoot);
+      } else {
+#pragma unroll
+        for (int f = 0; f < 4; f++) foot(f, contact[f], hmax[f], phase[f], air[f], first_contact[f], peak[f]);
       }
       float moving = cmd_norm > 0.01f ? 1.f : 0.f;
       rew[PGTT_R_FEET_SLIP] = slip * moving; rew[PGTT_R_FEET_CLEARANCE] = clear;
@@ -728,7 +762,7 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
 #pragma unroll
     for (int f = 0; f < 4; f++) { t.phase[f] = phase[f]; t.air[f] = air[f]; t.peak[f] = peak[f]; t.hmax[f] = hmax[f]; t.last_contact[f] = last_contact[f]; t.contact[f] = contact[f]; t.first_contact[f] = first_contact[f]; }
     t.phase_dt = phase_dt; t.step_ctr = step_ctr; t.timer = timer;
-    task_rewards(sh_st, sh_fr, sh_act, cfg, m, baseline, a.seed, id, ep, dt, t);
+    task_rewards<true>(sh_st, sh_fr, sh_act, cfg, m, baseline, a.seed, id, ep, dt, t);
 #pragma unroll
     for (int i = 0; i < 3; i++) cmd[i] = t.cmd[i];
 #pragma unroll
@@ -873,7 +907,7 @@ __global__ __launch_bounds__(64) void task_kernel(KArgs a, const float* __restri
     hist_v[i] = upd ? nv : st[PGTT_S_QVEL_HIST + i];
     hist_q[i] = upd ? nq : st[PGTT_S_QERR_HIST + i];
   }
-  task_rewards(st, fr, act, cfg, m, baseline, a.seed, id, ep, dt, t);
+  task_rewards<false>(st, fr, act, cfg, m, baseline, a.seed, id, ep, dt, t);
   // Episode / AutoReset wrapper semantics
   bool wdone = t.done;
   if (cfg->autoreset) {

@@ -12,6 +12,6 @@ for v in 1_0_0_0 1_0_0_1 1_0_1_0 1_0_1_1 1_1_0_0 1_1_0_1 1_1_1_0 1_1_1_1 4_0_0_0
   hipcc $F -DPG_SUBS=$s -DPG_MODE=$m -DPG_DR=$d -DPG_TERRAIN=$t -c pgtt_physics_inst.hip -o $root/alt_build/$out/p_$v.o 2>$root/alt_build/$out/p_$v.log &
   if [ "$v" = "1_1_1_1" ]; then wait; fi
 done
-hipcc $F -c pgtt_api.hip -o $root/alt_build/$out/api.o 2>/dev/null &
+hipcc ${F//-mllvm -amdgpu-sched-strategy=iterative-ilp/} -c pgtt_api.hip -o $root/alt_build/$out/api.o 2>/dev/null &     # the api kernels keep the default scheduler (Makefile)
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o $root/alt_build/libpgtt_$out.so $root/alt_build/$out/*.o && echo built alt_build/libpgtt_$out.so
