@@ -334,9 +334,13 @@ PG_INL float wave_min(float v) {
 // direction in the box frame lv = -R[2][:] is the same for every ray of a box: its reciprocals are formed once per box
 // (v_rcp_f32, 1 ulp) and the six face parameters are (side - lp) * (1 / lv) instead of six divisions per ray; an
 // axis-parallel component gives 1 / (+-0) = +-inf and the same +-inf / NaN face parameters as the division.
-struct RayBox { float il[3]; };
+struct RayBox { float il[3]; bool upright; };
 PG_INL RayBox ray_box_prepare(const TerrainBox& tb) {
-  return RayBox{{__builtin_amdgcn_rcpf(-tb.m20), __builtin_amdgcn_rcpf(-tb.m21), __builtin_amdgcn_rcpf(-tb.m22)}};
+  // upright: the box z axis is the world z axis (every shipped / generated terrain: boxes are only turned about z).  The ray
+  // then runs along the box z axis, the four side faces give +-inf / NaN parameters and are never valid, and the generic
+  // test reduces - bit for bit - to its two z faces.
+  return RayBox{{__builtin_amdgcn_rcpf(-tb.m20), __builtin_amdgcn_rcpf(-tb.m21), __builtin_amdgcn_rcpf(-tb.m22)},
+                tb.m20 == 0.f && tb.m21 == 0.f && fabsf(tb.m22) == 1.0f};
 }
 PG_INL float ray_box_down(const TerrainBox& tb, const RayBox& rb, V3 p) {
   V3 rel = p - v3(tb.px, tb.py, tb.pz);
@@ -345,6 +349,13 @@ PG_INL float ray_box_down(const TerrainBox& tb, const RayBox& rb, V3 p) {
   float lv[3] = {-tb.m20, -tb.m21, -tb.m22};
   float sz[3] = {tb.sx, tb.sy, tb.sz};
   float best = INFINITY;
+  if (rb.upright) {           // wave-uniform (the box record sits in scalar registers)
+    const bool inside = (fabsf(lp[0]) <= sz[0]) & (fabsf(lp[1]) <= sz[1]);      // p0 = lp[0] + x * (-0) = lp[0], p1 likewise
+    const float xt = (sz[2] - lp[2]) * rb.il[2], xb = (-sz[2] - lp[2]) * rb.il[2];
+    best = (inside & (xt >= 0.f)) ? xt : best;
+    best = (inside & (xb >= 0.f) & (xb < best)) ? xb : best;
+    return best;
+  }
 #pragma unroll
   for (int f = 0; f < 6; f++) {
     const int ax = f % 3, i0 = ax == 0 ? 1 : 0, i1 = ax == 2 ? 1 : 2;
