@@ -704,23 +704,36 @@ __global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __res
   PG_OTICK(3);
   // ---------------- observation rows in LDS (joystick_pgtt.py:336-365)
   const float lvl = cfg->noise_level;
+  // The noise draws of all rows in ONE Philox pass: the 147 noisy rows need 38 counter blocks (gyro 1, gravity 1, joint
+  // positions 3, joint velocities 3, scan 30; rng_uniform(.., stream, idx) is word idx & 3 of block idx >> 2), lane j forms
+  // block j and parks its four words in LDS - same draws as one rng_uniform call per row, a third of the multiplies.
+  __shared__ unsigned sh_rng[64 * 4];
+  static_assert(8 + (PGTT_NSCAN + 3) / 4 <= 64, "one lane per Philox block");
+  {
+    const int stream = lane == 0 ? PGTT_RS_GYRO : (lane == 1 ? PGTT_RS_GRAVITY : (lane < 5 ? PGTT_RS_QPOS : (lane < 8 ? PGTT_RS_QVEL : PGTT_RS_SCAN)));
+    const int blk = lane < 2 ? 0 : (lane < 5 ? lane - 2 : (lane < 8 ? lane - 5 : lane - 8));
+    unsigned c0 = id, c1 = ep, c2 = (unsigned)stream, c3 = (unsigned)blk;
+    philox4x32_10((unsigned)a.seed, (unsigned)(a.seed >> 32), c0, c1, c2, c3);
+    sh_rng[4 * lane + 0] = c0; sh_rng[4 * lane + 1] = c1; sh_rng[4 * lane + 2] = c2; sh_rng[4 * lane + 3] = c3;
+  }
+  __syncthreads();
   for (int io = lane; io < OBSD; io += 64) {
     // i = row in the PGTT layout; the baseline layout drops rows 30..37 (phase) and 38 + NSCAN (gait_freq)
     const int i = !baseline ? io : (io < 30 ? io : (io < 30 + PGTT_NSCAN ? io + 8 : io + 9));
-    // every row is (base + noise) - offset with noise = (2u - 1) * level * scale: the arms only pick the operands, the
-    // Philox draw is made ONCE per row (rows without noise draw too, with scale 0)
-    float base, scale = 0.f, offs = 0.f; int stream = PGTT_RS_GYRO, sidx = 0;
-    if (i < 3) { base = sh_fr[PGTT_F_GYRO + i]; stream = PGTT_RS_GYRO; sidx = i; scale = cfg->noise_gyro; }
-    else if (i < 6) { base = sh_fr[PGTT_F_GRAVITY + i - 3]; stream = PGTT_RS_GRAVITY; sidx = i - 3; scale = cfg->noise_gravity; }
-    else if (i < 18) { base = sh_st[PGTT_S_QPOS + 7 + i - 6]; stream = PGTT_RS_QPOS; sidx = i - 6; scale = cfg->noise_joint_pos; offs = m->key_qpos[7 + i - 6]; }
-    else if (i < 30) { base = sh_st[PGTT_S_QVEL + 6 + i - 18]; stream = PGTT_RS_QVEL; sidx = i - 18; scale = cfg->noise_joint_vel; }
+    // every row is (base + noise) - offset with noise = (2u - 1) * level * scale: the arms only pick the operands and the
+    // word of sh_rng that holds the row's draw (rows without noise read a word too, with scale 0)
+    float base, scale = 0.f, offs = 0.f; int rblk = 0, sidx = 0;       // rblk: lane that formed block 0 of the row's stream
+    if (i < 3) { base = sh_fr[PGTT_F_GYRO + i]; rblk = 0; sidx = i; scale = cfg->noise_gyro; }
+    else if (i < 6) { base = sh_fr[PGTT_F_GRAVITY + i - 3]; rblk = 1; sidx = i - 3; scale = cfg->noise_gravity; }
+    else if (i < 18) { base = sh_st[PGTT_S_QPOS + 7 + i - 6]; rblk = 2; sidx = i - 6; scale = cfg->noise_joint_pos; offs = m->key_qpos[7 + i - 6]; }
+    else if (i < 30) { base = sh_st[PGTT_S_QVEL + 6 + i - 18]; rblk = 5; sidx = i - 18; scale = cfg->noise_joint_vel; }
     else if (i < 34) base = cosf(sel4(i - 30, phase[0], phase[1], phase[2], phase[3]));
     else if (i < 38) base = sinf(sel4(i - 34, phase[0], phase[1], phase[2], phase[3]));
-    else if (i < 38 + PGTT_NSCAN) { base = sh_scan[i - 38] - zmin; stream = PGTT_RS_SCAN; sidx = i - 38; scale = cfg->noise_heightscan; }
+    else if (i < 38 + PGTT_NSCAN) { base = sh_scan[i - 38] - zmin; rblk = 8; sidx = i - 38; scale = cfg->noise_heightscan; }
     else if (i == 38 + PGTT_NSCAN) base = gait_freq;
     else if (i < 39 + PGTT_NSCAN + 12) base = sh_st[PGTT_S_LAST_ACT + i - (39 + PGTT_NSCAN)];
     else base = sel4(i - (51 + PGTT_NSCAN), cmd[0], cmd[1], cmd[2], 0.f);
-    const float u = rng_uniform(a.seed, id, ep, (unsigned)stream, sidx);
+    const float u = (float)(sh_rng[4 * rblk + sidx] >> 8) * (1.0f / 16777216.0f);      // word sidx & 3 of block rblk + (sidx >> 2)
     const float noisy = scale != 0.f ? base + (2.f * u - 1.f) * lvl * scale : base;
     const float v = offs != 0.f ? noisy - offs : noisy;
     sh_obs[io] = v;
