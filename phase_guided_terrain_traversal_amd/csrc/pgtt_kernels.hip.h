@@ -524,7 +524,8 @@ PG_INL void task_rewards(const float* sh_st, const float* sh_fr, const float* sh
 #define PG_OTICK(i) ((void)0)
 #endif
 template <int OMODE, bool HAS_TERRAIN>
-__global__ __launch_bounds__(64) void observe_kernel(KArgs a, const float* __restrict__ action) {
+// four waves per SIMD (128 VGPRs): the kernel is latency-bound, a launch lasts as long as the resident waves of a SIMD take in turn
+__global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __restrict__ action) {
   const int e = xcd_block(blockIdx.x, gridDim.x), lane = threadIdx.x, N = a.N;
 #ifdef PGTT_TIME
   const long long ot0_ = __builtin_readcyclecounter();
