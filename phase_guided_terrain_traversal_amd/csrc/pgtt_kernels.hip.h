@@ -319,15 +319,21 @@ __global__ __launch_bounds__(64) void reset_pose_kernel(KArgs a) {
 // OBS_STEP_OBS: the scan + observation half of a step (rewards / bookkeeping are done by task_kernel, one env per LANE)
 enum { OBS_STEP = 0, OBS_SCAN_LIFT = 1, OBS_RESET = 2, OBS_SCAN_ONLY = 3, OBS_STEP_OBS = 4 };
 
+// wave-wide max / min (all 64 lanes active): DPP butterflies inside the 16-lane rows, then the four row results through
+// scalar registers - no LDS crossbar (ds_bpermute) round trips
 PG_INL float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+  v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x124>(v)); v = fmaxf(v, dpp_f<0x128>(v));
+  const int i = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(i, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(i, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 PG_INL float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-  return v;
+  v = fminf(v, dpp_f<0xB1>(v)); v = fminf(v, dpp_f<0x4E>(v)); v = fminf(v, dpp_f<0x124>(v)); v = fminf(v, dpp_f<0x128>(v));
+  const int i = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(i, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(i, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
+  return fminf(fminf(r0, r1), fminf(r2, r3));
 }
 
 // vertical ray (0,0,-1) from world point p against one terrain box; generic mjx _ray_box in the box frame.  The ray
