@@ -397,9 +397,10 @@ struct QPhysics {
     s.qb[3] = q0.w; s.qb[4] = q0.x; s.qb[5] = q0.y; s.qb[6] = q0.z;
     s.p0 = v3(s.qb[0], s.qb[1], s.qb[2]);
     s.R0 = qmat(q0);
-    body_inertia(0, s.p0, q0, em.base_ipos, em.mass0, xi0, Iw0);
+    if (kSubs == 1) body_inertia(0, s.p0, q0, em.base_ipos, em.mass0, xi0, Iw0);
     s.imu = s.p0 + qrot(v3(m->imu_pos[0], m->imu_pos[1], m->imu_pos[2]), q0);
     V3 pp = s.p0; Q4 pq = q0;
+    V3 lpos[3]; Q4 lq[3];          // link frames (hex layout: the world inertias are formed afterwards, one body per sub-lane)
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       const int j = 3 * l + k, mb = 1 + j;
@@ -410,8 +411,26 @@ struct QPhysics {
       s.axis[k] = qrot(ax, pq);
       s.anchor[k] = pos;
       Q4 xq = qmul(pq, Q4{cs, ax.x * sn, ax.y * sn, ax.z * sn});
-      body_inertia(mb, pos, xq, v3(m->body_ipos[mb][0], m->body_ipos[mb][1], m->body_ipos[mb][2]), em.massl[k], xil[k], Iwl[k]);
+      if (kSubs == 1) body_inertia(mb, pos, xq, v3(m->body_ipos[mb][0], m->body_ipos[mb][1], m->body_ipos[mb][2]), em.massl[k], xil[k], Iwl[k]);
+      lpos[k] = pos; lq[k] = xq;
       pp = pos; pq = xq;
+    }
+    if (kSubs == 4) {
+      // hex layout: the four sub-lanes of a leg held four copies of the same four world inertias (3 links + base, ~100
+      // instructions each); sub-lane r now forms the one of body r (3 = the base) and hands it round - same arithmetic per
+      // body, so every lane ends with the same bits as before
+      const int r = threadIdx.x & 3;
+      const int mbr = r == 3 ? 0 : 1 + 3 * l + r;
+      const V3 xp = v3(sel4(r, lpos[0].x, lpos[1].x, lpos[2].x, s.p0.x), sel4(r, lpos[0].y, lpos[1].y, lpos[2].y, s.p0.y), sel4(r, lpos[0].z, lpos[1].z, lpos[2].z, s.p0.z));
+      const Q4 xq{sel4(r, lq[0].w, lq[1].w, lq[2].w, q0.w), sel4(r, lq[0].x, lq[1].x, lq[2].x, q0.x), sel4(r, lq[0].y, lq[1].y, lq[2].y, q0.y), sel4(r, lq[0].z, lq[1].z, lq[2].z, q0.z)};
+      const V3 ipl = v3(m->body_ipos[mbr][0], m->body_ipos[mbr][1], m->body_ipos[mbr][2]);
+      const V3 ipos = r == 3 ? em.base_ipos : ipl;
+      V3 xi; float Iw[6];
+      body_inertia(mbr, xp, xq, ipos, 0.f, xi, Iw);
+      xil[0] = v3(sub_bcast<0>(xi.x), sub_bcast<0>(xi.y), sub_bcast<0>(xi.z)); xil[1] = v3(sub_bcast<1>(xi.x), sub_bcast<1>(xi.y), sub_bcast<1>(xi.z));
+      xil[2] = v3(sub_bcast<2>(xi.x), sub_bcast<2>(xi.y), sub_bcast<2>(xi.z)); xi0 = v3(sub_bcast<3>(xi.x), sub_bcast<3>(xi.y), sub_bcast<3>(xi.z));
+#pragma unroll
+      for (int i = 0; i < 6; i++) { Iwl[0][i] = sub_bcast<0>(Iw[i]); Iwl[1][i] = sub_bcast<1>(Iw[i]); Iwl[2][i] = sub_bcast<2>(Iw[i]); Iw0[i] = sub_bcast<3>(Iw[i]); }
     }
     s.footc = pp + qrot(v3(m->foot_geom_pos[l][0], m->foot_geom_pos[l][1], m->foot_geom_pos[l][2]), pq);
     s.sitef = pp + qrot(v3(m->foot_site_pos[l][0], m->foot_site_pos[l][1], m->foot_site_pos[l][2]), pq);
