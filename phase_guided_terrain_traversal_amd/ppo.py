@@ -14,6 +14,7 @@ measured inside a real training loop and `train.py` keeps the reference's CLI.  
 from __future__ import annotations
 
 import math
+import os
 import time
 from dataclasses import dataclass
 from typing import Callable, Dict, Optional
@@ -181,6 +182,10 @@ class _Learner:
         self.idx = torch.zeros(mb, dtype=torch.long, device=B["obs"].device)
         self.loss = torch.zeros((), device=B["obs"].device)
         self.use_graph, self.graph, self.calls = use_graph, None, 0
+        # the value branch (its own MLP, its own inputs) runs on a side stream next to the policy branch, forward and - since
+        # autograd replays a node on the stream of its forward - backward: the ~150 launches of an update are 4-30 us each
+        # and launch-latency bound, two independent chains overlap
+        self.side = torch.cuda.Stream(device=B["obs"].device) if os.environ.get("PGTT_PPO_STREAMS", "2") == "2" else None
 
     def _loss(self):
         B, idx, cfg, model = self.B, self.idx, self.cfg, self.model
@@ -190,14 +195,28 @@ class _Learner:
         a = (a - a.mean()) / (a.std() + 1e-8)
         ratio = torch.exp(logp - B["logp"][idx])
         pol = -torch.min(ratio * a, torch.clamp(ratio, 1 - cfg.clipping_epsilon, 1 + cfg.clipping_epsilon) * a).mean()
-        v = model.value(self.norm_p(B["priv"][idx])).squeeze(-1)
-        v_loss = 0.5 * 0.5 * ((B["ret"][idx] - v) ** 2).mean()
         ent = model.entropy(loc, scale, loc + scale * torch.randn_like(loc)).mean()
-        return pol + v_loss - cfg.entropy_cost * ent
+        return pol - cfg.entropy_cost * ent
+
+    def _value_loss(self):
+        B, idx = self.B, self.idx
+        v = self.model.value(self.norm_p(B["priv"][idx])).squeeze(-1)
+        return 0.5 * 0.5 * ((B["ret"][idx] - v) ** 2).mean()
+
+    def _total_loss(self):
+        if self.side is None:
+            return self._loss() + self._value_loss()
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            v_loss = self._value_loss()
+        pol = self._loss()
+        main.wait_stream(self.side)
+        return pol + v_loss
 
     def _eager(self):
         self.opt.zero_grad(set_to_none=True)
-        loss = self._loss()
+        loss = self._total_loss()
         loss.backward()
         nn.utils.clip_grad_norm_(self.model.parameters(), self.cfg.max_grad_norm)
         self.opt.step()
@@ -225,7 +244,7 @@ class _Learner:
         return self.loss
 
     def _eager_body_for_capture(self):
-        loss = self._loss()
+        loss = self._total_loss()
         loss.backward()
         nn.utils.clip_grad_norm_(self.model.parameters(), self.cfg.max_grad_norm)
         self.opt.step()
