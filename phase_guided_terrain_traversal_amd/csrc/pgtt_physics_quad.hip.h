@@ -902,13 +902,27 @@ struct QPhysics {
     // scan order leg-major): MJX's sequential top-k picks exactly the pairs that fewer than max_contact_points others
     // beat, so every lane only ranks its OWN pairs against the table — no selection rounds.
     const int nslot = (maxc > -1 && maxc < 4) ? maxc : 4;
-    bool mine[kMaxPenQ];
-    {
-      bool ok[4][kMaxPenQ];
+    bool ok[4][kMaxPenQ];
 #pragma unroll
-      for (int i = 0; i < kMaxPenQ; i++)
+    for (int i = 0; i < kMaxPenQ; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) ok[j][i] = (cdist[j][i] < 0.f) & !((broad & need_exact) & (crank[j][i] >= maxp));
+      for (int j = 0; j < 4; j++) ok[j][i] = (cdist[j][i] < 0.f) & !((broad & need_exact) & (crank[j][i] >= maxp));
+    // is the own pair (d, rank r, scan order ord) among the nslot best of the env's table?
+    auto selected = [&](float d, int r, bool okm, int ord) {
+      int beat = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i2 = 0; i2 < kMaxPenQ; i2++) {
+          if (i2 >= ncol) continue;
+          const bool first = (cdist[j][i2] < d) | ((cdist[j][i2] == d) & ((crank[j][i2] < r) | ((crank[j][i2] == r) & (j * kMaxPenQ + i2 < ord))));
+          beat += (ok[j][i2] & first) ? 1 : 0;
+        }
+      return okm & (beat < nslot);
+    };
+    int nb = 0;
+    if (kSubs == 1) {
+      bool mine[kMaxPenQ];
 #pragma unroll
       for (int i = 0; i < kMaxPenQ; i++) {
         if (i >= ncol) { mine[i] = false; continue; }
@@ -916,31 +930,45 @@ struct QPhysics {
         const float d = sel4(l, cdist[0][i], cdist[1][i], cdist[2][i], cdist[3][i]);
         const int r = l == 0 ? crank[0][i] : (l == 1 ? crank[1][i] : (l == 2 ? crank[2][i] : crank[3][i]));
         const bool okm = l == 0 ? ok[0][i] : (l == 1 ? ok[1][i] : (l == 2 ? ok[2][i] : ok[3][i]));
-        const int ord = l * kMaxPenQ + i;
-        int beat = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-          for (int i2 = 0; i2 < kMaxPenQ; i2++) {
-            if (i2 >= ncol) continue;
-            const bool first = (cdist[j][i2] < d) | ((cdist[j][i2] == d) & ((crank[j][i2] < r) | ((crank[j][i2] == r) & (j * kMaxPenQ + i2 < ord))));
-            beat += (ok[j][i2] & first) ? 1 : 0;
-          }
-        mine[i] = okm & (beat < nslot);
+        mine[i] = selected(d, r, okm, l * kMaxPenQ + i);
       }
-    }
-    // own selected pairs: park (dist, box, point, normal) in the slot records
-    int nb = 0;
+      // own selected pairs: park (dist, box, point, normal) in the slot records
 #pragma unroll
-    for (int i = 0; i < kMaxPenQ; i++) {
-      if (i >= ncol) continue;
-      if (mine[i]) {
-        slots.at(nb, 0) = pen[i].dist;
-        slots.at(nb, 20) = __int_as_float(pen[i].idx - l * nbox);
-        // point / normal move down from entry i to slot nb <= i (entries below i were consumed already)
+      for (int i = 0; i < kMaxPenQ; i++) {
+        if (i >= ncol) continue;
+        if (mine[i]) {
+          slots.at(nb, 0) = pen[i].dist;
+          slots.at(nb, 20) = __int_as_float(pen[i].idx - l * nbox);
+          // point / normal move down from entry i to slot nb <= i (entries below i were consumed already)
 #pragma unroll
-        for (int f = 7; f <= 12; f++) { const float v = slots.at(i, f); slots.at(nb, f) = v; }
-        nb++;
+          for (int f = 7; f <= 12; f++) { const float v = slots.at(i, f); slots.at(nb, f) = v; }
+          nb++;
+        }
+      }
+    } else {
+      // hex layout: sub-lane q ranks the leg's pair q and moves it - one pass whatever the number of candidate columns.
+      // All sub-lanes READ their entry before any of them writes a slot (the LDS executes a wave's accesses in program
+      // order), so a pair moving down into the entry of another one is safe.
+      const int q = threadIdx.x & 3;
+      const float d = sel4(q, pen[0].dist, pen[1].dist, pen[2].dist, pen[3].dist);       // = cdist[l][q], the own leg's column of the table
+      auto seli = [&](int a0, int a1, int a2, int a3, int k) { return k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : a3)); };
+      const int r = seli(seli(crank[0][0], crank[1][0], crank[2][0], crank[3][0], l), seli(crank[0][1], crank[1][1], crank[2][1], crank[3][1], l),
+                         seli(crank[0][2], crank[1][2], crank[2][2], crank[3][2], l), seli(crank[0][3], crank[1][3], crank[2][3], crank[3][3], l), q);
+      const bool okm = (d < 0.f) & !((broad & need_exact) & (r >= maxp));
+      const bool mine_q = (q < ncol) & selected(d, r, okm, l * kMaxPenQ + q);
+      const int mi = mine_q ? 1 : 0;
+      const int m0 = sub_bcast<0>(mi), m1 = sub_bcast<1>(mi), m2 = sub_bcast<2>(mi), m3 = sub_bcast<3>(mi);
+      const int dest = q == 0 ? 0 : (q == 1 ? m0 : (q == 2 ? m0 + m1 : m0 + m1 + m2));      // selected pairs below the own one
+      nb = m0 + m1 + m2 + m3;
+      float mv[6];
+#pragma unroll
+      for (int f = 0; f < 6; f++) mv[f] = slots.at(q, 7 + f);
+      const int iq = seli(pen[0].idx, pen[1].idx, pen[2].idx, pen[3].idx, q);
+      if (mine_q) {
+        slots.at(dest, 0) = d;
+        slots.at(dest, 20) = __int_as_float(iq - l * nbox);
+#pragma unroll
+        for (int f = 0; f < 6; f++) slots.at(dest, 7 + f) = mv[f];
       }
     }
     s.nbox = nb;
