@@ -799,20 +799,20 @@ struct QPhysics {
     }
     PG_TICK(s, 13);
     if (__ballot(npen > 0) == 0ull) return;
-    // candidate table of the whole quad (replicated): key/idx/dist of lane j's i-th penetrating pair
-    float ckey[4][kMaxPenQ], cdist[4][kMaxPenQ]; int cidx[4][kMaxPenQ], crank[4][kMaxPenQ];
-#pragma unroll
-    for (int i = 0; i < kMaxPenQ; i++) {
-      ckey[0][i] = quad_bcast<0>(pen[i].key); ckey[1][i] = quad_bcast<1>(pen[i].key); ckey[2][i] = quad_bcast<2>(pen[i].key); ckey[3][i] = quad_bcast<3>(pen[i].key);
-      cdist[0][i] = quad_bcast<0>(pen[i].dist); cdist[1][i] = quad_bcast<1>(pen[i].dist); cdist[2][i] = quad_bcast<2>(pen[i].dist); cdist[3][i] = quad_bcast<3>(pen[i].dist);
-      cidx[0][i] = quad_bcast<0>(pen[i].idx); cidx[1][i] = quad_bcast<1>(pen[i].idx); cidx[2][i] = quad_bcast<2>(pen[i].idx); cidx[3][i] = quad_bcast<3>(pen[i].idx);
-#pragma unroll
-      for (int j = 0; j < 4; j++) crank[j][i] = 0;
-    }
     // wave-uniform number of candidate columns that are in use anywhere
     int ncol = 0;
 #pragma unroll
     for (int i = 0; i < kMaxPenQ; i++) if (__ballot(npen > i) != 0ull) ncol = i + 1;
+    // candidate table of the whole quad (replicated): depth of lane j's i-th penetrating pair (columns in use only); the keys
+    // and indices of the table are fetched by the exact-rank pass alone
+    float cdist[4][kMaxPenQ]; int crank[4][kMaxPenQ];
+#pragma unroll
+    for (int i = 0; i < kMaxPenQ; i++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) { cdist[j][i] = 1.f; crank[j][i] = 0; }
+      if (i >= ncol) continue;
+      cdist[0][i] = quad_bcast<0>(pen[i].dist); cdist[1][i] = quad_bcast<1>(pen[i].dist); cdist[2][i] = quad_bcast<2>(pen[i].dist); cdist[3][i] = quad_bcast<3>(pen[i].dist);
+    }
     bool need_exact = false;
     unsigned nearmask = 0u;
     if (broad) {
@@ -849,9 +849,13 @@ struct QPhysics {
       };
       unsigned long long cpk[4][kMaxPenQ];
 #pragma unroll
-      for (int i = 0; i < kMaxPenQ; i++)
+      for (int i = 0; i < kMaxPenQ; i++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) cpk[j][i] = packed(ckey[j][i], cidx[j][i]);
+        for (int j = 0; j < 4; j++) cpk[j][i] = ~0ull;
+        if (i >= ncol) continue;
+        cpk[0][i] = packed(quad_bcast<0>(pen[i].key), quad_bcast<0>(pen[i].idx)); cpk[1][i] = packed(quad_bcast<1>(pen[i].key), quad_bcast<1>(pen[i].idx));
+        cpk[2][i] = packed(quad_bcast<2>(pen[i].key), quad_bcast<2>(pen[i].idx)); cpk[3][i] = packed(quad_bcast<3>(pen[i].key), quad_bcast<3>(pen[i].idx));
+      }
       auto rank_against = [&](unsigned long long pk) {
 #pragma unroll
         for (int i = 0; i < kMaxPenQ; i++) {
