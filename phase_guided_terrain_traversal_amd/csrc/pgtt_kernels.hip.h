@@ -124,6 +124,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
       sh_box[b * kEnvsPerWave + quad] = make_float4(tb->px, tb->py, tb->pz, tb->hx);
       sh_box2[b * kEnvsPerWave + quad] = make_float2(tb->hy, tb->hz);
     }
+    slots.clear_all();
     __syncthreads();
   }
   s.niter = 0; s.niter_max = 0;

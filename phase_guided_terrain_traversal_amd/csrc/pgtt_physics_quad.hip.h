@@ -147,6 +147,12 @@ struct BoxSlots {
     c.box = __float_as_int(at(k, 20));
     return c;
   }
+  PG_INL void clear_all() const {       // once per launch: LDS comes up uninitialised, and stale NaNs would survive 0 * x
+#pragma unroll
+    for (int k = 0; k < kMaxB; k++)
+#pragma unroll
+      for (int f = 0; f < kSlotFields; f++) at(k, f) = f == 0 ? 1.f : (f == 20 ? __int_as_float(-2) : 0.f);
+  }
   PG_INL float& jar(int k, int r) const { return at(k, 21 + r); }
   PG_INL float& jv(int k, int r) const { return at(k, 25 + r); }
 };
@@ -671,10 +677,15 @@ struct QPhysics {
     s.nbox = 0;
     if (boxes == nullptr || nbox <= 0) return;
     PG_TICK(s, 11);
-    {
-      QContact z; clear_contact(z);
+    // a slot that is not used in this substep must contribute exact zeros: no active row, D = 0, aref = 0.  Its other fields
+    // (mu, offset, frame) only ever meet those zeros and keep whatever finite values they hold (the records are cleared in
+    // full once per launch, BoxSlots::clear_all)
 #pragma unroll
-      for (int k = 0; k < kMaxB; k++) slots.store(k, z);
+    for (int k = 0; k < kMaxB; k++) {
+      slots.at(k, 2) = 0.f;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; r4++) slots.at(k, 3 + r4) = 0.f;
+      slots.at(k, 19) = __int_as_float(0);
     }
     const int maxp = m->max_geom_pairs, maxc = m->max_contact_points;
     const bool broad = maxp > -1 && 4 * nbox > maxp;
