@@ -136,6 +136,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
 #endif
   const int nsub = MODE == MODE_STEP ? cfg->n_substeps : 1;
   const float dt = m->timestep;
+  PG_TICK(s, 15);          // launch prologue: state rows, per-env model, LDS staging of the terrain variant
   for (int sub = 0; sub < nsub; sub++) {
     PG_TICK(s, 9);
     ph.kinematics();

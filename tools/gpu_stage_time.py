@@ -14,7 +14,7 @@ env = Joystick("flat_terrain" if wl == "flat" else "stairs", configs.training_co
 env.reset(seed=1)
 L = native.lib(); L.pgtt_trace_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
 g = torch.Generator(device="cuda").manual_seed(0)
-names = ["position", "velocity", "constraint", "sensors", "solver init x2-3", "first gradient", "line search", "update_constraint", "update_gradient", "rest/integrate", "iterations", "  c: limits+plane", "  c: AABB pass 1a", "  c: narrow 1b", "  c: table+count 2a/2b", "  c: selection", "  c: contact records", "-"]
+names = ["position", "velocity", "constraint", "sensors", "solver init x2-3", "first gradient", "line search", "update_constraint", "update_gradient", "rest/integrate", "iterations", "  c: limits+plane", "  c: AABB pass 1a", "  c: narrow 1b", "  c: table+count 2a/2b", "  launch prologue", "  c: contact records", "-"]
 acc = np.zeros(22)
 for k in range(60):
     act = torch.tanh(torch.randn(n, 12, device="cuda", generator=g) * 0.6)

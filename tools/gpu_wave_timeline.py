@@ -33,7 +33,7 @@ for k in range(330):
         for c in sorted(set(multi.tolist())):
             print(f"   waves sharing their SIMD with {c - 1} others: {np.sum(multi == c):4d}, mean duration {np.mean((e - s)[multi == c]):.0f} ns")
         st = seg[16384:16384 + 24 * 1024].reshape(1024, 24)[:len(tw)]
-        names = ["position", "velocity", "constraint", "sensors", "solver init", "first gradient", "line search", "update_constraint", "update_gradient", "rest", "newton trips", "c:limits+plane", "c:AABB", "c:narrow", "c:table+count", "c:selection", "c:records", "sum nslots", "ls rounds", "ls needed"]
+        names = ["position", "velocity", "constraint", "sensors", "solver init", "first gradient", "line search", "update_constraint", "update_gradient", "rest", "newton trips", "c:limits+plane", "c:AABB", "c:narrow", "c:table+count", "prologue", "c:records", "sum nslots", "ls rounds", "ls needed"]
         order = np.argsort(-(e - s))
         med = np.median(st, axis=0)
         print("   stage ticks: " + "  ".join(f"{names[i]}={med[i]:.0f}" for i in range(20)) + "   <- median wave")
