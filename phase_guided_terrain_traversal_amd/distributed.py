@@ -45,6 +45,7 @@ class MetricReducer:
         self.device = device
         self.acc = torch.zeros(self.SIZE, dtype=torch.float32, device=device)
         self.count = 0.0          # env-steps accumulated since the last reduce (kept on the host: no kernel per step)
+        self._ones = None
 
     def accumulate(self, metrics: torch.Tensor, reward: torch.Tensor, done: torch.Tensor) -> None:
         """metrics [22, N], reward [N], done [N] of one step (local shard)."""
@@ -54,9 +55,13 @@ class MetricReducer:
         self.count += float(reward.shape[0])
 
     def accumulate_block(self, block: torch.Tensor) -> None:
-        """`Joystick.step_block` ([22 metrics; reward; done][N]) of one step: one reduction kernel + one add."""
-        self.acc[:abi.NMETRIC + 2] += block.sum(dim=1)
-        self.count += float(block.shape[1])
+        """`Joystick.step_block` ([22 metrics; reward; done][N]) of one step: ONE launch, acc += block @ 1 (GEMV with
+        beta = 1) instead of a reduction kernel plus an add (~5 us of a 0.24 ms step each)."""
+        n = block.shape[1]
+        if self._ones is None or self._ones.shape[0] != n:
+            self._ones = torch.ones(n, dtype=torch.float32, device=block.device)
+        self.acc[:abi.NMETRIC + 2].addmv_(block, self._ones)
+        self.count += float(n)
 
     def reduce(self) -> Dict[str, torch.Tensor]:
         """Sum over ranks (one RCCL all-reduce), reset the local accumulator, return global means."""
