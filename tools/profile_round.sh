@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/${ROUND_TAG:-r01n}; mkdir -p $O
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/${ROUND_TAG:-r01o}; mkdir -p $O
 python bench.py > $O/bench_level4.json 2>$O/bench_level4.err
 python bench.py --workload flat --no-cpu-baseline > $O/bench_flat.json 2>/dev/null
 python bench.py --workload wfc_dr --envs 8192 --no-cpu-baseline > $O/bench_wfc_dr_8192.json 2>/dev/null
