@@ -268,6 +268,15 @@ int pgtt_obs_dims(const PgttConfig* cfg, int* state_dim, int* priv_dim);
 int pgtt_sizeof_model(void);
 int pgtt_sizeof_config(void);
 int pgtt_sizeof_buffers(void);
+/* Trainer-side helper (not part of the env step; replaces no reference entry point - the reference's PPO is Brax's):
+ * the policy part of the PPO minibatch loss, -mean(min(r a, clip(r) a)) - entropy_cost * mean(entropy), of a tanh-normal
+ * policy head (loc | raw scale, scale = softplus(raw) + 1e-3; the Brax loss configured at training/train.py:135-161) and its
+ * gradient with respect to the network output, in one launch + a single-wave finish instead of ~100 elementwise launches.
+ * All pointers are device pointers (float32); partial holds 2 * ceil(B / 64) floats of scratch; loss_3 = {total, policy
+ * term, mean entropy}; A must be 12.  Enqueued on `stream`, no synchronisation. */
+int pgtt_ppo_policy_loss(const float* out_Bx2A, const float* u_BxA, const float* logp_old_B, const float* adv_B,
+                         const float* eps_BxA, int B, int A, float clip_eps, float entropy_cost,
+                         float* partial_2xceilB64, float* loss_3, float* grad_Bx2A, void* stream);
 const char* pgtt_version(void);
 const char* pgtt_last_error(void);
 

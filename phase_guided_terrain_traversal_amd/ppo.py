@@ -94,6 +94,33 @@ class ActorCritic(nn.Module):
         return ent.sum(-1)
 
 
+class _FusedPolicyLoss(torch.autograd.Function):
+    """Policy part of the PPO loss through libpgtt's pgtt_ppo_policy_loss (one HIP launch + a finish instead of ~100
+    elementwise launches forward and backward).  Same arithmetic as `_Learner._loss_torch`; tests/test_gpu_train.py compares."""
+
+    @staticmethod
+    def forward(ctx, out, u, logp_old, adv, eps, clip, cost):
+        from . import native
+        import ctypes
+        out, u, logp_old, adv, eps = (t.contiguous() for t in (out, u, logp_old, adv, eps))
+        B, A = u.shape
+        grad = torch.empty_like(out)
+        partial = torch.empty(2 * ((B + 63) // 64), dtype=torch.float32, device=out.device)
+        loss = torch.empty(3, dtype=torch.float32, device=out.device)
+        native.check(native.lib().pgtt_ppo_policy_loss(
+            ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(u.data_ptr()), ctypes.c_void_p(logp_old.data_ptr()),
+            ctypes.c_void_p(adv.data_ptr()), ctypes.c_void_p(eps.data_ptr()), ctypes.c_int(B), ctypes.c_int(A),
+            ctypes.c_float(clip), ctypes.c_float(cost), ctypes.c_void_p(partial.data_ptr()), ctypes.c_void_p(loss.data_ptr()),
+            ctypes.c_void_p(grad.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)))
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None, None, None
+
+
 @dataclass
 class PPOConfig:
     num_timesteps: int = 300_000_000
@@ -188,6 +215,17 @@ class _Learner:
         self.side = torch.cuda.Stream(device=B["obs"].device) if os.environ.get("PGTT_PPO_STREAMS", "2") == "2" else None
 
     def _loss(self):
+        """policy part of the loss: fused HIP kernel (PGTT_PPO_FUSED=0: the PyTorch-op form below)"""
+        if os.environ.get("PGTT_PPO_FUSED", "1") == "0":
+            return self._loss_torch()
+        B, idx, cfg, model = self.B, self.idx, self.cfg, self.model
+        out = model.policy(self.norm_s(B["obs"][idx]))
+        a = B["adv"][idx]
+        a = (a - a.mean()) / (a.std() + 1e-8)
+        eps = torch.randn(out.shape[0], out.shape[1] // 2, dtype=out.dtype, device=out.device)
+        return _FusedPolicyLoss.apply(out, B["u"][idx], B["logp"][idx], a, eps, float(cfg.clipping_epsilon), float(cfg.entropy_cost))
+
+    def _loss_torch(self):
         B, idx, cfg, model = self.B, self.idx, self.cfg, self.model
         loc, scale = model.dist(self.norm_s(B["obs"][idx]))
         logp = model.log_prob(loc, scale, B["u"][idx])
