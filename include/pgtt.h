@@ -277,6 +277,11 @@ int pgtt_sizeof_buffers(void);
 int pgtt_ppo_policy_loss(const float* out_Bx2A, const float* u_BxA, const float* logp_old_B, const float* adv_B,
                          const float* eps_BxA, int B, int A, float clip_eps, float entropy_cost,
                          float* partial_2xceilB64, float* loss_3, float* grad_Bx2A, void* stream);
+/* Trainer-side helper: weight and bias gradient of a Linear layer over a long batch, dW[n][m] = sum_k dY[k][n] X[k][m],
+ * db[n] = sum_k dY[k][n] (X [K][M], dY [K][N], dW in torch's [N][M] layout), K split over S workgroups per 64x64 tile on
+ * fp32 MFMA, summed in a fixed order.  partial holds S * (N * M + N) floats of scratch.  Device pointers, caller's stream. */
+int pgtt_ppo_linear_backward(const float* x_KxM, const float* dy_KxN, int K, int M, int N, int S,
+                             float* partial_Sx_NM_plus_N, float* dw_NxM, float* db_N, void* stream);
 const char* pgtt_version(void);
 const char* pgtt_last_error(void);
 

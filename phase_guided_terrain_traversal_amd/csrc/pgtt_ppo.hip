@@ -87,3 +87,98 @@ extern "C" int pgtt_ppo_policy_loss(const float* out_Bx2A, const float* u_BxA, c
   hipLaunchKernelGGL(ppo_policy_loss_finish, dim3(1), dim3(64), 0, st, partial_2xceilB64, nb, B, entropy_cost, loss_3);
   return hipGetLastError() == hipSuccess ? PGTT_OK : PGTT_E_HIP;
 }
+
+// ------------------------------------------------------------------ weight / bias gradient of a Linear layer over a long batch
+// dW[n][m] = sum_k dY[k][n] X[k][m],  db[n] = sum_k dY[k][n]   (X: [K][M] activations, dY: [K][N], torch weight layout [N][M])
+// K is the minibatch (5120 rows), M and N are 1..512: the library GEMM picked for this shape walks K in a handful of
+// workgroups (34 us whatever M x N) and the bias gradient is a second 15 us reduction.  Here K is split over S workgroups per
+// 64x64 output tile (one wave each, 2x2 v_mfma_f32_32x32x2_f32 blocks, exact fp32), the column sums of dY ride along, and a
+// second launch adds the S partial planes in a fixed order (deterministic; no atomics).
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(64) void linear_bwd_partial_kernel(const float* __restrict__ X, const float* __restrict__ dY, int K, int M, int N,
+                                                                int kc, float* __restrict__ Pw, float* __restrict__ Pb) {
+  const int lane = threadIdx.x, half = lane >> 5, col = lane & 31;
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64, s = blockIdx.z;
+  const int kbeg = s * kc, kend = min(K, kbeg + kc);
+  // operand columns of this lane (clamped; out-of-range columns are multiplied by 0)
+  const int na = n0 + col, nb = n0 + 32 + col, ma = m0 + col, mb = m0 + 32 + col;
+  const float fna = na < N ? 1.f : 0.f, fnb = nb < N ? 1.f : 0.f, fma_ = ma < M ? 1.f : 0.f, fmb = mb < M ? 1.f : 0.f;
+  const int cna = na < N ? na : N - 1, cnb = nb < N ? nb : N - 1, cma = ma < M ? ma : M - 1, cmb = mb < M ? mb : M - 1;
+  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+  float sa = 0.f, sb = 0.f;
+  // wave-uniform trip count (an MFMA needs both half-waves); eight k-pairs per trip, all 32 operand loads issued before the
+  // 32 MFMAs (scheduling fence) so that one memory latency is paid per trip, not per pair
+  constexpr int T = 8;
+  for (int k2 = kbeg; k2 < kend; k2 += 2 * T) {
+    float a0[T], a1[T], b0[T], b1[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+      const int k = k2 + 2 * t + half;
+      const int kk = k < kend ? k : kend - 1;
+      a0[t] = dY[(long)kk * N + cna]; a1[t] = dY[(long)kk * N + cnb];
+      b0[t] = X[(long)kk * M + cma]; b1[t] = X[(long)kk * M + cmb];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+      const float kv = k2 + 2 * t + half < kend ? 1.f : 0.f;           // tail: zeros
+      const float x0 = a0[t] * (fna * kv), x1 = a1[t] * (fnb * kv), y0 = b0[t] * fma_, y1 = b1[t] * fmb;
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, acc11, 0, 0, 0);
+      sa += x0; sb += x1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float* pw = Pw + (long)s * N * M;
+  auto put = [&](const f32x16& acc, int nbase, int mbase) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int n = nbase + (r & 3) + 8 * (r >> 2) + 4 * half, m = mbase + col;       // C/D map of the 32x32 forms: row, column
+      if (n < N && m < M) pw[(long)n * M + m] = acc[r];
+    }
+  };
+  put(acc00, n0, m0); put(acc01, n0, m0 + 32); put(acc10, n0 + 32, m0); put(acc11, n0 + 32, m0 + 32);
+  if (blockIdx.x == 0) {                       // column sums of dY: the two half-waves hold the even / odd rows
+    sa += __shfl_xor(sa, 32); sb += __shfl_xor(sb, 32);
+    if (half == 0) { if (na < N) Pb[(long)s * N + na] = sa; if (nb < N) Pb[(long)s * N + nb] = sb; }
+  }
+}
+
+__global__ __launch_bounds__(256) void linear_bwd_reduce_kernel(const float* __restrict__ Pw, const float* __restrict__ Pb, int S, int NM, int N,
+                                                                float* __restrict__ dW, float* __restrict__ db) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < NM) {
+    float v = 0.f;
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {                         // eight planes in flight, added in plane order
+      float p[8];
+#pragma unroll
+      for (int t = 0; t < 8; t++) p[t] = Pw[(long)(s + t) * NM + i];
+#pragma unroll
+      for (int t = 0; t < 8; t++) v += p[t];
+    }
+    for (; s < S; s++) v += Pw[(long)s * NM + i];
+    dW[i] = v;
+  }
+  if (i < N) { float v = 0.f; for (int s = 0; s < S; s++) v += Pb[(long)s * N + i]; db[i] = v; }
+}
+
+}  // namespace
+
+extern "C" int pgtt_ppo_linear_backward(const float* x_KxM, const float* dy_KxN, int K, int M, int N, int S,
+                                        float* partial_Sx_NM_plus_N, float* dw_NxM, float* db_N, void* stream) {
+  if (!x_KxM || !dy_KxN || !partial_Sx_NM_plus_N || !dw_NxM || !db_N || K <= 0 || M <= 0 || N <= 0 || S <= 0) return PGTT_E_ARG;
+  int kc = (K + S - 1) / S; kc += kc & 1;                       // even chunk: both half-waves start on their own parity
+  const int Sused = (K + kc - 1) / kc;
+  float* Pw = partial_Sx_NM_plus_N; float* Pb = partial_Sx_NM_plus_N + (long)S * N * M;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(linear_bwd_partial_kernel, dim3((M + 63) / 64, (N + 63) / 64, Sused), dim3(64), 0, st, x_KxM, dy_KxN, K, M, N, kc, Pw, Pb);
+  const int NM = N * M;
+  hipLaunchKernelGGL(linear_bwd_reduce_kernel, dim3((NM + 255) / 256), dim3(256), 0, st, Pw, Pb, Sused, NM, N, dw_NxM, db_N);
+  return hipGetLastError() == hipSuccess ? PGTT_OK : PGTT_E_HIP;
+}

@@ -14,7 +14,7 @@ _LIB: Optional[C.CDLL] = None
 
 EXPORTS = ["pgtt_create", "pgtt_destroy", "pgtt_set_terrain", "pgtt_bind", "pgtt_reset", "pgtt_step",
            "pgtt_physics", "pgtt_observe", "pgtt_scan", "pgtt_enable_timing", "pgtt_last_kernel_ms", "pgtt_kernel_ms_mean",
-           "pgtt_ppo_policy_loss", "pgtt_obs_dims", "pgtt_sizeof_model", "pgtt_sizeof_config", "pgtt_sizeof_buffers", "pgtt_version", "pgtt_last_error"]
+           "pgtt_ppo_policy_loss", "pgtt_ppo_linear_backward", "pgtt_obs_dims", "pgtt_sizeof_model", "pgtt_sizeof_config", "pgtt_sizeof_buffers", "pgtt_version", "pgtt_last_error"]
 
 
 class PgttError(RuntimeError):

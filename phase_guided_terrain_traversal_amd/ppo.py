@@ -60,12 +60,52 @@ class RunningNorm:
         return (x - self.mean) / self.std
 
 
+class _LinearLongBatch(torch.autograd.Function):
+    """y = x W^T + b with the weight / bias gradient through libpgtt's pgtt_ppo_linear_backward (split-K fp32 MFMA, the
+    column sums of dY in the same launch): for K = 5120 rows and 1..512 columns the library GEMM walks K in a handful of
+    workgroups (34 us whatever the size) and the bias gradient is a second reduction."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import native
+        import ctypes
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous(); x = x.contiguous()
+        K, M = x.shape
+        N = w.shape[0]
+        dx = dy @ w if ctx.needs_input_grad[0] else None
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        S = max(1, min(64, int(os.environ.get("PGTT_PPO_SPLITK", "768")) // tiles, K // 16))
+        partial = torch.empty(S * (N * M + N), dtype=torch.float32, device=x.device)
+        dw = torch.empty_like(w); db = torch.empty(N, dtype=torch.float32, device=x.device)
+        native.check(native.lib().pgtt_ppo_linear_backward(
+            ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(dy.data_ptr()), ctypes.c_int(K), ctypes.c_int(M), ctypes.c_int(N), ctypes.c_int(S),
+            ctypes.c_void_p(partial.data_ptr()), ctypes.c_void_p(dw.data_ptr()), ctypes.c_void_p(db.data_ptr()),
+            ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        return dx, dw, db
+
+
+class LongBatchLinear(nn.Linear):
+    """nn.Linear (same parameters, same state_dict) whose backward over a long batch runs on the hand-written kernel."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dim() == 2 and x.shape[0] >= 1024 and torch.is_grad_enabled() and self.weight.requires_grad
+                and x.dtype == torch.float32 and os.environ.get("PGTT_PPO_FUSED", "1") != "0" and os.environ.get("PGTT_PPO_LINEAR", "1") != "0"):
+            return _LinearLongBatch.apply(x, self.weight, self.bias)
+        return F.linear(x, self.weight, self.bias)
+
+
 def mlp(sizes, out):
     layers, d = [], sizes[0]
     for h in sizes[1:]:
-        layers += [nn.Linear(d, h), nn.SiLU()]
+        layers += [LongBatchLinear(d, h), nn.SiLU()]
         d = h
-    layers.append(nn.Linear(d, out))
+    layers.append(LongBatchLinear(d, out))
     return nn.Sequential(*layers)
 
 

@@ -69,3 +69,21 @@ def test_fused_policy_loss_matches_autograd():
     assert int(edge.sum()) < 40
     frac_clipped = float(((torch.exp(logp_now - logp_old) - 1).abs() > clip).float().mean())
     assert 0.2 < frac_clipped < 0.8
+
+
+@pytest.mark.parametrize("shape", [(5120, 171, 512), (5120, 512, 256), (5120, 256, 128), (5120, 128, 24), (5120, 128, 1), (1031, 215, 512)])
+def test_long_batch_linear_backward_matches_autograd(shape):
+    """pgtt_ppo_linear_backward (split-K fp32 MFMA + column sums) against torch's Linear backward: dX, dW, db"""
+    from phase_guided_terrain_traversal_amd import ppo
+    K, M, N = shape
+    g = torch.Generator(device="cuda").manual_seed(K + M + N)
+    x = torch.randn(K, M, device="cuda", generator=g)
+    up = torch.randn(K, N, device="cuda", generator=g)
+    lin_a = torch.nn.Linear(M, N).cuda(); lin_b = ppo.LongBatchLinear(M, N).cuda()
+    lin_b.load_state_dict(lin_a.state_dict())
+    xa = x.clone().requires_grad_(True); xb = x.clone().requires_grad_(True)
+    (lin_a(xa) * up).sum().backward(); (lin_b(xb) * up).sum().backward()
+    torch.cuda.synchronize()
+    for name, ra, rb in (("dx", xa.grad, xb.grad), ("dw", lin_a.weight.grad, lin_b.weight.grad), ("db", lin_a.bias.grad, lin_b.bias.grad)):
+        scale = float(ra.abs().max())
+        assert float((ra - rb).abs().max()) < 2e-5 * scale * (K ** 0.5) / 10 + 1e-6, (name, float((ra - rb).abs().max()), scale)
