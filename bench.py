@@ -7,14 +7,27 @@ A "step" is one control step (4 physics substeps + 13x9 scan + obs + 21 rewards 
 Episode/AutoReset wrapper fused) over the per-GPU batch of synthetic actions.  Workload = BASELINE.json
 configs[2]: 4096 Go2 envs per GPU on terrains/level4.npy with the height scan, no DR (the configuration the
 metric "env-steps/sec at 4096 envs (Go2, level4 hfield)" is quoted on).  Weak scaling: every GPU owns 4096
-envs; the only collective is the 25-float metric all-reduce every 20 steps.
+envs; the only collective is the 25-float metric all-reduce every 20 steps (RCCL).
+
+Launch: under torchrun the ranks come from the environment; a bare `python bench.py --gpus N` (N > 1) SPAWNS the
+N ranks itself (one process per GPU) and refuses when the node has fewer than N devices.
+
+Before the clock starts the whole timed loop body runs at least once per code path whatever --warmup says (one pass
+over the action pool with the kernel events recorded on every step, the per-step metric GEMV, two fused all-reduces):
+nothing in the timed window loads a code object or creates an event for the first time.  `wall_over_kernels` =
+ms_per_step / (physics + observe + metric GEMV kernel time); "cold": true (and exit code 3) when it exceeds 1.5.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (physics_kernel); `cpu_baseline` is the
 build's own CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded sample.
+
+`--backend gloo` is a TEST HOOK (tests/test_distributed.py): CPU tensors and a stub env, so that the rank / barrier /
+MAX-over-ranks / rank-0-print path of this file runs without a GPU; its line carries "stub": true and is not a result.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,12 +40,14 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_ENV_STEP = 3456          # no-DR workload; 4216 with per-env DR params
 ALGO_BYTES_PER_ENV_STEP_DR = 4216
 ALGO_FLOP_PER_ENV_STEP = 1.6e6          # fp32, dense MJX formulation (the reference's arithmetic)
-PEAK_FP32_TFLOPS = 157.3                # MI355X fp32: matrix peak == vector peak (MI355X_MICROARCH.md)
+PEAK_FP32_TFLOPS = 157.3                # MI355X fp32 vector peak (MI355X_MICROARCH.md); the fp32 matrix peak is the same number
 PEAK_HBM_GBS = 8000.0
 CURRICULUM = [1, 2, 3, 4, 7, 10, 13]    # the level files the reference ships (terrains/level*.npy), easiest first
+REDUCE_EVERY = 20                       # log interval of the metric all-reduce (unroll length of training/train.py:142)
+COLD_RATIO = 1.5
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -42,20 +57,51 @@ def main():
     ap.add_argument("--stage", type=int, default=None, help="curriculum workload: index into the level list (default: the rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-steps", type=int, default=100)
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU test hook with a stub env (not a result)")
+    return ap.parse_args(argv)
 
+
+class StubEnv:
+    """CPU stand-in with the surface of env.Joystick that the bench loop touches (test hook for --backend gloo)."""
+
+    def __init__(self, n, rank):
+        import torch
+        from phase_guided_terrain_traversal_amd import abi
+        self.num_envs = n
+        self.step_block = torch.zeros((abi.NMETRIC + 2, n), dtype=torch.float32)
+        self.buffers = {"done": self.step_block[abi.NMETRIC + 1]}
+        self._k, self._timed, self._rank = 0, 0, rank
+
+    def reset(self, seed=0):
+        self._k = 0
+
+    def step(self, action):
+        self._k += 1
+        self.step_block[:-2] = action.mean()
+        self.step_block[-2] = 1.0 + self._rank      # "reward": rank-dependent so the all-reduce is checkable
+        self.step_block[-1] = 0.0
+        if self._timing:
+            self._timed += 1
+        return None, self.step_block[-2], self.step_block[-1], {}
+
+    _timing = 0
+
+    def enable_timing(self, on=True):
+        self._timing, self._timed = int(on), 0
+
+    def kernel_ms_mean(self):
+        return 1e-3, 1e-3, max(self._timed, 1)
+
+    def close(self):
+        pass
+
+
+def build_env(args, rank, world, local):
+    """the workload of BASELINE.json configs[1..4] on this rank's shard -> (env, terrain, task, dr)"""
     import torch
-    import torch.distributed as dist
-    from phase_guided_terrain_traversal_amd import abi, configs, mjcf
-    from phase_guided_terrain_traversal_amd.distributed import MetricReducer, init_from_env
+    from phase_guided_terrain_traversal_amd import configs, mjcf
     from phase_guided_terrain_traversal_amd.env import Joystick
     from phase_guided_terrain_traversal_amd.randomize import domain_randomize
-
-    rank, local, world = init_from_env("nccl")
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
     n = args.envs
     off = rank * n
     assets = os.path.join(ROOT, "phase_guided_terrain_traversal_amd", "assets", "terrains")
@@ -80,44 +126,95 @@ def main():
         kw = {"variant": torch.from_numpy(out["variant"]), "params": torch.from_numpy(out["params"]),
               "box_friction": torch.from_numpy(out["box_friction"])}
     env = Joystick(task, cfg, num_envs=n, terrain=terrain, device=f"cuda:{local}", autoreset=True, env_id_offset=off, **kw)
+    return env, cfg, terrain, task, dr
+
+
+def worker(args):
+    import torch
+    import torch.distributed as dist
+    from phase_guided_terrain_traversal_amd.distributed import MetricReducer, init_from_env
+
+    stub = args.backend == "gloo"
+    rank, local, world = init_from_env(args.backend)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}` without a torchrun environment: it spawns the ranks)")
+    if stub:
+        dev = torch.device("cpu")
+        env, cfg, terrain, task, dr = StubEnv(args.envs, rank), None, None, "stub", False
+        sync = lambda: None
+    else:
+        if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
+            raise SystemExit(f"rank {rank}: no GPU {local} (device_count = {torch.cuda.device_count() if torch.cuda.is_available() else 0}); "
+                             "the bench has no CPU path")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        env, cfg, terrain, task, dr = build_env(args, rank, world, local)
+        sync = torch.cuda.synchronize
+    n = args.envs
     env.reset(seed=0)
     g = torch.Generator(device=dev); g.manual_seed(1 + rank)
     pool = [torch.tanh(torch.randn(n, 12, generator=g, device=dev) * 0.6) for _ in range(32)]   # tanh(N(0,0.6)), SURVEY 8d
     reducer = MetricReducer(dev)
+    env_steps_seen = torch.zeros((), dtype=torch.float64, device=dev)     # sum of the all-reduced env-step counts
 
     def run(k0, k1):
         for k in range(k0, k1):
-            obs, reward, done, info = env.step(pool[k % len(pool)])
+            env.step(pool[k % len(pool)])
             reducer.accumulate_block(env.step_block)
-            if (k + 1) % 20 == 0:
-                reducer.reduce()
+            if (k + 1) % REDUCE_EVERY == 0:
+                env_steps_seen.add_(reducer.reduce()["env_steps"])
 
-    run(0, args.warmup)
-    torch.cuda.synchronize()
-    # per-kernel durations over the timed steps themselves: HIP events recorded by libpgtt around its own launches on
-    # the launch stream (every 8th step), kept in a ring and read back later (no stall in the timed loop)
+    # ---- prime: every code path of the timed loop, whatever --warmup is (the driver runs --steps 20 --warmup 5)
+    env.enable_timing(1)                                   # events recorded around the kernels of EVERY step
+    run(0, max(len(pool), 2 * REDUCE_EVERY))               # full pass over the pool, >= 2 all-reduces
+    sync()
+    env.kernel_ms_mean()                                   # the read-back path of the event ring
+    gemv_ms = 0.0
+    if not stub:                                           # duration of the per-step metric GEMV (torch launch on the same stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(16):
+            reducer.accumulate_block(env.step_block)
+        e1.record(); sync()
+        gemv_ms = e0.elapsed_time(e1) / 16
+    reducer.reduce(); env_steps_seen.zero_()               # counters back to zero
+    # ---- the W untimed warm-up steps of the contract
     env.enable_timing(8)          # every 8th step: an event record costs a few us of GPU idle
+    run(0, args.warmup)
+    sync()
+    if args.warmup % REDUCE_EVERY:
+        reducer.reduce()
+    env_steps_seen.zero_()
+    env.enable_timing(8)                                   # timing counters back to zero: means are over the timed steps only
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
-    run(args.warmup, args.warmup + args.steps)
-    torch.cuda.synchronize()
+    run(0, args.steps)
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
+    ranks = 1
+    if args.steps % REDUCE_EVERY:
+        env_steps_seen.add_(reducer.reduce()["env_steps"])  # the tail of the last interval (outside the clock)
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor([dt, 1.0], device=dev, dtype=torch.float64)
+        tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        ts = t.clone(); dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+        dt, ranks = float(tm[0].item()), int(round(float(ts[1].item())))
     phys_ms, obs_ms, ntimed = env.kernel_ms_mean()
     env.enable_timing(False)
     done_frac = float(env.buffers["done"].mean().item())
+    env_steps = float(env_steps_seen.item())
 
+    rc = 0
     if rank == 0:
-        total_envs = n * world
-        value = total_envs * args.steps / dt
+        value = env_steps / dt               # env-steps the all-reduce counted over ALL ranks / max-over-ranks wall time
+        kern = phys_ms + obs_ms + gemv_ms
+        ratio = 1e3 * dt / args.steps / kern
         algo_bytes = (ALGO_BYTES_PER_ENV_STEP_DR if dr else ALGO_BYTES_PER_ENV_STEP) * n
         algo_flop = ALGO_FLOP_PER_ENV_STEP * n
         traffic = None
@@ -129,7 +226,7 @@ def main():
                 traffic = None
         out = {
             "metric": "env-steps/sec at 4096 envs (Go2, level4 hfield), 1/2/4/8 MI355X",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "env-steps/s", "n_gpus": ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": {"level4": "4096 Go2 envs/GPU, terrains/level4.npy (100 variants x 100 boxes) + 13x9 height scan, no DR (BASELINE configs[2])",
@@ -137,21 +234,34 @@ def main():
                                     "level13_dr": "Go2 envs/GPU, level13 + full randomize.py DR (BASELINE configs[3] shape)",
                                     "curriculum": "Go2 envs/GPU, rank r on stage r of terrains/level{1,2,3,4,7,10,13}.npy + height scan, no DR (BASELINE configs[4])",
                                     "wfc_dr": "Go2 envs/GPU, WFC-generated stairs (terrain_gen.py, 100 variants) + full randomize.py DR (BASELINE configs[3])"}[args.workload],
-                       "envs_per_gpu": n, "substeps": 4, "autoreset": True, "actions": "tanh(N(0,0.6)) iid", "parallelism": f"env-shard x{world}"},
-            "kernels_ms": {"physics_kernel": phys_ms, "observe_kernel": obs_ms, "launches": ntimed},
+                       "envs_per_gpu": n, "substeps": 4, "autoreset": True, "actions": "tanh(N(0,0.6)) iid", "parallelism": f"env-shard x{world}",
+                       "collective": f"fused {MetricReducer.SIZE}-float all-reduce every {REDUCE_EVERY} steps ({args.backend})"},
+            "env_steps_allreduced": env_steps, "env_steps_expected": float(n) * world * args.steps,
+            "kernels_ms": {"physics_kernel": phys_ms, "observe_kernel": obs_ms, "metric_gemv": gemv_ms, "launches": ntimed},
+            "wall_over_kernels": ratio, "cold": bool(ratio > COLD_RATIO),
             "done_fraction_last_step": done_frac,
-            "roofline": {"bound": "mfma", "achieved": algo_flop / (phys_ms * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "valu_fp32", "achieved": algo_flop / (phys_ms * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": algo_flop / (phys_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "kernel": "physics_kernel", "note": "fp32: matrix peak == vector peak (157.3 TF); kernel is FP32-VALU/latency bound, no MFMA issued"},
+                         "kernel": "physics_kernel", "note": "FP32 vector-ALU issue / latency bound (SURVEY 8d); algorithmic flops = dense-MJX count 1.6 MFLOP per env-step"},
             "roofline_hbm": {"bound": "hbm", "achieved": algo_bytes / (phys_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": algo_bytes / (phys_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": traffic},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if stub:
+            out.update(stub=True, roofline=None, roofline_hbm=None, kernels_ms=None)
+        if env_steps != float(n) * world * args.steps or ranks != world:
+            out["error"] = f"all-reduce saw {env_steps} env-steps from {ranks} ranks, expected {float(n) * world * args.steps} from {world}"
+            rc = 4
+        if world == 1 and not args.no_cpu_baseline and not stub:
             out["cpu_baseline"] = cpu_baseline(args, cfg, terrain, task, n)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+        if out["cold"] and not stub:
+            print(f"bench.py: wall time is {ratio:.2f} x the kernel time: the timed window is not kernel-bound (cold code or host-bound launch loop)", file=sys.stderr)
+            rc = rc or 3
     env.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return rc
 
 
 def host_cores():
@@ -168,10 +278,13 @@ def host_cores():
 
 
 def cpu_baseline(args, cfg, terrain, task, n):
-    """The build's CPU restatement (oracle/, fp32, OpenMP over envs) on a bounded sample of the same workload."""
+    """The build's CPU restatement (oracle/, fp32, OpenMP over envs) on a bounded sample of the same workload.
+    Built ON THIS HOST with -O3 -march=native (`make -C oracle fast`), which cannot travel between
+    machines; when no compiler is at hand the portable -O2 build the tests use is timed and the line says so."""
     from oracle import oracle
-    from phase_guided_terrain_traversal_amd import abi, configs, mjcf
+    from phase_guided_terrain_traversal_amd import abi, mjcf
     cores = host_cores()
+    flags = oracle.use_fast_build()
     cfg2 = dict(cfg); cfg2["autoreset"] = 1
     cs, ms = abi.config_struct(cfg2), abi.model_struct(mjcf.load_model(task))
     hb = oracle.HostBuffers(n, with_variant=terrain is not None, debug=False)
@@ -187,8 +300,37 @@ def cpu_baseline(args, cfg, terrain, task, n):
         oracle.step(cs, ms, terrain, hb, acts[k % 8], seed=0, nthreads=cores)
     dt = time.perf_counter() - t0
     return {"value": n * args.cpu_sample_steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} envs x {args.cpu_sample_steps} control steps of the same workload ({args.workload}), fp32 oracle, OpenMP over envs, {dt:.1f} s"}
+            "sample": f"{n} envs x {args.cpu_sample_steps} control steps of the same workload ({args.workload}), fp32 oracle ({flags}), OpenMP over envs, {dt:.1f} s"}
+
+
+def _spawned(i, argv, port, n):
+    os.environ.update(RANK=str(i), LOCAL_RANK=str(i), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rc = worker(parse_args(argv))
+    if rc:
+        sys.exit(rc)
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` outside torchrun: one process per GPU, rendezvous on 127.0.0.1"""
+    import torch
+    import torch.multiprocessing as mp
+    if args.backend == "nccl":
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this node has {have} GPU(s); refusing to run fewer ranks than asked for")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_spawned, args=(argv, port, args.gpus), nprocs=args.gpus, join=True)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args, argv)
+        return 0
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

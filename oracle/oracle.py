@@ -19,12 +19,34 @@ def build() -> None:
     subprocess.run(["make", "-C", _HERE, "-s"], check=True)
 
 
-def lib() -> C.CDLL:
+def use_fast_build() -> str:
+    """bench.py's cpu_baseline leg only: compile the oracle on THIS host with -O3 -march=native (`make fast`)
+    and route the following calls through it.  Returns the flags of the build that will be timed; falls back to the
+    portable -O2 -ffp-contract=off checker build when no compiler is available."""
     global _LIB
+    try:
+        subprocess.run(["make", "-C", _HERE, "-s", "fast"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _LIB = None
+        _load(os.path.join(_HERE, "_fast", "liboracle_fast.so"))
+        return "gcc -O3 -march=native, built on this host"
+    except Exception:
+        _LIB = None
+        lib()
+        return "gcc -O2 -ffp-contract=off portable build (no compiler on this host for -march=native)"
+
+
+def lib() -> C.CDLL:
     if _LIB is None:
         path = os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(path):
             build()
+        _load(path)
+    return _LIB
+
+
+def _load(path: str) -> C.CDLL:
+    global _LIB
+    if True:
         _LIB = C.CDLL(path)
         _LIB.pgtt_oracle_get_z.restype = C.c_double
         _LIB.pgtt_oracle_get_z.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int]

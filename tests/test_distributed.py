@@ -71,3 +71,50 @@ def test_gloo_world2_metric_allreduce(tmp_path):
         outs.append(json.loads(o.strip().splitlines()[-1]))
     assert all(o["ok"] for o in outs)
     assert sorted((o["lo"], o["hi"]) for o in outs) == [(0, 500), (500, 1000)]
+
+
+def _bench_line(out):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out          # ONE JSON line, from rank 0 only
+    import json
+    return json.loads(lines[0])
+
+
+def test_bench_loop_world2_spawned_gloo():
+    """`python bench.py --gpus 2` outside torchrun spawns the two ranks itself; the bench loop (prime, warm-up, barrier,
+    timed steps with the fused all-reduce every 20 steps, MAX over ranks, rank-0 print) runs on the gloo test hook"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "45",
+                        "--warmup", "5", "--envs", "64"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _bench_line(p.stdout)
+    assert d["stub"] is True and d["n_gpus"] == 2 and d["steps"] == 45 and d["warmup"] == 5
+    # the all-reduced env-step count proves both ranks contributed every interval, tail included (45 = 2 x 20 + 5)
+    assert d["env_steps_allreduced"] == d["env_steps_expected"] == 2 * 64 * 45
+    assert abs(d["value"] - d["env_steps_allreduced"] / (d["ms_per_step"] * 1e-3 * 45)) < 1e-6 * d["value"]
+
+
+def test_bench_loop_world2_torchrun_env_gloo():
+    """the driver's launch form: ranks from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run)"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29612", WORLD_SIZE="2")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "20", "--warmup", "3", "--envs", "32"]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    d = _bench_line(outs[0][0])
+    assert d["n_gpus"] == 2 and d["env_steps_allreduced"] == 2 * 32 * 20
+    assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]      # rank 1 prints nothing
+
+
+def test_bench_refuses_fewer_gpus_than_asked():
+    """no silent single-rank run: --gpus 8 on a node with fewer devices is an error, and so is a WORLD_SIZE mismatch"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    import torch
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 8:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode != 0 and "refusing" in p.stderr
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--steps", "2", "--warmup", "1"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
