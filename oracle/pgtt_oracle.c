@@ -6,6 +6,11 @@
  *
  * Build: make -C oracle   (gcc, -O2, -ffp-contract=off so the f32 build is plain IEEE fp32)
  */
+/* per-iteration solver trace for single-env replays (tools only): records of 3 doubles, (1000 + iter, cost, |grad|/scale) at the top of
+   each Newton trip and (alpha, ls rounds, d0 at the accepted point) after each line search */
+double* g_oracle_trace = 0; int g_oracle_trace_n = 0;
+void pgtt_oracle_set_trace(double* buf4000_or_null) { g_oracle_trace = buf4000_or_null; g_oracle_trace_n = 0; }
+int pgtt_oracle_trace_len(void) { return g_oracle_trace_n; }
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -223,6 +228,11 @@ typedef struct PgttOraclePostIn {
   int32_t contact[4];
 } PgttOraclePostIn;
 
+/* diagnostic side channel of the batch step (tests / tools): when set, step e writes the largest scaled gradient norm at the
+   solver's exit over its substeps into g_diag_resid[e] */
+static double* g_diag_resid = NULL;
+void pgtt_oracle_set_diag(double* resid_N_or_null) { g_diag_resid = resid_N_or_null; }
+
 /* ================================================================ batch drivers over the PgttBuffers SoA layout (HOST pointers) */
 #define BATCH(SUF, RT)                                                                                                   \
   static void gather_##SUF(const PgttBuffers* B, long N, long e, OData_##SUF* d, OInfo_##SUF* in) {                      \
@@ -327,6 +337,7 @@ typedef struct PgttOraclePostIn {
       if (prev_done) in.ep_steps = 0;                                                                                    \
       task_step_##SUF(&c, d, &in, act, obs, priv, &reward, &done, metrics, contact);                                     \
       write_frame_##SUF(B, N, e, d, contact); write_dbg_##SUF(B, e, d);                                                  \
+      if (g_diag_resid) g_diag_resid[e] = (double)d->solver_resid_max;                                                   \
       int idone = done != 0;                                                                                             \
       if (cfg->autoreset) {                                                                                              \
         in.ep_steps += 1;                                                                                                \

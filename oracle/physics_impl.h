@@ -79,6 +79,7 @@ typedef struct F(OData) {
   R qacc[ONV], efc_force[ONEFC], qfrc_constraint[ONV];
   int solver_niter;
   int solver_niter_max;          /* max over the substeps of env_step */
+  R solver_resid, solver_resid_max;   /* scaled gradient norm at the solver's exit (diagnostic: how far from the minimiser the cut solve is) */
   R cacc_base[6];
   R sensordata[49];
 } F(OData);
@@ -748,6 +749,7 @@ static inline int F(in_bracket)(const F(OLSPoint)* x, const F(OLSPoint)* y) {
   return ((x->deriv0 < y->deriv0) && (y->deriv0 < 0)) || ((x->deriv0 > y->deriv0) && (y->deriv0 > 0));
 }
 static void F(linesearch)(const PgttModel* m, const F(OData)* d, F(OCtx)* c) {
+  extern double* g_oracle_trace; extern int g_oracle_trace_n;
   R snorm = 0; for (int i = 0; i < ONV; i++) snorm += c->search[i]*c->search[i];
   R smag = SQRT(snorm)*(R)m->meaninertia*(R)(ONV > 1 ? ONV : 1);
   R gtol = (R)m->tolerance*(R)m->ls_tolerance*smag;
@@ -790,11 +792,13 @@ static void F(linesearch)(const PgttModel* m, const F(OData)* d, F(OCtx)* c) {
   int improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
   R alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
   R ia = improved ? alpha : 0;
+  if (g_oracle_trace && g_oracle_trace_n < 4000) { g_oracle_trace[g_oracle_trace_n++] = (double)ia; g_oracle_trace[g_oracle_trace_n++] = (double)it; g_oracle_trace[g_oracle_trace_n++] = (double)(lo.cost < hi.cost ? lo.deriv0 : hi.deriv0); }
   for (int i = 0; i < ONV; i++) { c->qacc[i] += c->search[i]*ia; c->Ma[i] += mv[i]*ia; }
   for (int r = 0; r < ONEFC; r++) c->Jaref[r] += jv[r]*ia;
 }
 
 static void F(solve)(const PgttModel* m, F(OData)* d) {
+  extern double* g_oracle_trace; extern int g_oracle_trace_n;
   F(OCtx) warm, smth, ctx;
   F(ctx_create)(d, d->qacc_warmstart, 0, &warm);
   F(ctx_create)(d, d->qacc_smooth, 0, &smth);
@@ -805,6 +809,7 @@ static void F(solve)(const PgttModel* m, F(OData)* d) {
     R improvement = (ctx.prev_cost - ctx.cost)/scale;
     R gn = 0; for (int i = 0; i < ONV; i++) gn += ctx.grad[i]*ctx.grad[i];
     R gradient = SQRT(gn)/scale;
+    if (g_oracle_trace && g_oracle_trace_n < 4000) { g_oracle_trace[g_oracle_trace_n++] = 1000 + ctx.niter; g_oracle_trace[g_oracle_trace_n++] = (double)ctx.cost; g_oracle_trace[g_oracle_trace_n++] = (double)gradient; }
     int done = ctx.niter >= m->iterations;
     done |= improvement < (R)m->tolerance;
     done |= gradient < (R)m->tolerance;
@@ -818,6 +823,7 @@ static void F(solve)(const PgttModel* m, F(OData)* d) {
   for (int i = 0; i < ONV; i++) { d->qacc[i] = ctx.qacc[i]; d->qacc_warmstart[i] = ctx.qacc[i]; d->qfrc_constraint[i] = ctx.qfrc_constraint[i]; }
   for (int r = 0; r < ONEFC; r++) d->efc_force[r] = ctx.efc_force[r];
   d->solver_niter = ctx.niter;
+  { R gn = 0; for (int i = 0; i < ONV; i++) gn += ctx.grad[i]*ctx.grad[i]; d->solver_resid = SQRT(gn)/scale; }
 }
 
 /* ------------------------------------------------------------------ sensors (mjx sensor.py) */
@@ -898,11 +904,12 @@ static void F(euler)(const PgttModel* m, F(OData)* d) {
 /* mjx_env.step(model, data, action, n_substeps): scan of { ctrl <- action ; mjx.step } */
 static void F(env_step)(const PgttModel* m, const F(OParams)* p, const float* boxes, const float* box_friction, int nbox,
                         F(OData)* d, const R* ctrl, int nsub) {
-  d->solver_niter_max = 0;
+  d->solver_niter_max = 0; d->solver_resid_max = 0;
   for (int s = 0; s < nsub; s++) {
     for (int a = 0; a < 12; a++) d->ctrl[a] = ctrl[a];
     F(forward)(m, p, boxes, box_friction, nbox, d);
     if (d->solver_niter > d->solver_niter_max) d->solver_niter_max = d->solver_niter;
+    if (d->solver_resid > d->solver_resid_max) d->solver_resid_max = d->solver_resid;
     F(euler)(m, d);
   }
 }

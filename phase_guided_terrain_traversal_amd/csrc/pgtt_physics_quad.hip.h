@@ -362,7 +362,13 @@ PG_INL void qload_env_model(const PgttModel* __restrict__ m, const float* __rest
   }
 }
 
-struct QPen { float dist, key; int idx; };     // a penetrating (foot, box) pair; its contact point and normal wait in LDS
+struct QPen { float dist, key; int idx; };
+// (broad-phase key, pair index) as one integer that sorts like the pair (key through the order-preserving float -> uint map)
+PG_INL unsigned long long packed_key(float key, int idx) {
+  const unsigned u = __float_as_uint(key);
+  const unsigned mono = u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
+  return ((unsigned long long)mono << 32) | (unsigned)idx;
+}     // a penetrating (foot, box) pair; its contact point and normal wait in LDS
 
 struct QPhysics {
   const PgttModel* __restrict__ m;
@@ -853,11 +859,7 @@ struct QPhysics {
       // one 64-bit integer (key through the order-preserving float -> uint map; keys are never -0 or NaN), so a
       // candidate costs one compare and one add per box; every lane counts over its own foot's pairs (hex: the boxes
       // go round the sub-lanes), the sums over the lanes of the env give the ranks.
-      auto packed = [](float key, int idx) {
-        const unsigned u = __float_as_uint(key);
-        const unsigned mono = u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
-        return ((unsigned long long)mono << 32) | (unsigned)idx;
-      };
+      auto packed = [](float key, int idx) { return packed_key(key, idx); };
       unsigned long long cpk[4][kMaxPenQ];
 #pragma unroll
       for (int i = 0; i < kMaxPenQ; i++) {
@@ -912,6 +914,31 @@ struct QPhysics {
         for (int j = 0; j < 4; j++) crank[j][i] = quad_sum_i(sub_sum_i(crank[j][i]));
       }
     }
+    else {
+      // Exact ranks were not needed for the max_geom_pairs cut, but lax.top_k is stable and MJX's narrow phase runs in
+      // broad-phase order, so EQUAL depths at the max_contact_points cut are still decided by rank (two boxes with a common
+      // top face under one foot give bit-identical depths).  The order of two candidates by rank is the order of their
+      // (key, pair index) pairs, and the pair index grows with the scan order of the table: when some env of the wave has
+      // more penetrating pairs than slots, the rank column is filled with the keys themselves (order-preserving float ->
+      // uint map; the selection compares ranks as unsigned numbers) - no tables beyond the ones that are live anyway.
+      int npn = 0;
+#pragma unroll
+      for (int i = 0; i < kMaxPenQ; i++) {
+        if (i >= ncol) continue;
+#pragma unroll
+        for (int j = 0; j < 4; j++) npn += cdist[j][i] < 0.f ? 1 : 0;
+      }
+      const int nslot0 = (maxc > -1 && maxc < 4) ? maxc : 4;
+      if (broad && __ballot(npn > nslot0) != 0ull) {
+#pragma unroll
+        for (int i = 0; i < kMaxPenQ; i++) {
+          if (i >= ncol) continue;
+          const unsigned u = __float_as_uint(pen[i].key);
+          const int mono = (int)(u ^ ((unsigned)((int)u >> 31) | 0x80000000u));
+          crank[0][i] = quad_bcast<0>(mono); crank[1][i] = quad_bcast<1>(mono); crank[2][i] = quad_bcast<2>(mono); crank[3][i] = quad_bcast<3>(mono);
+        }
+      }
+    }
     PG_TICK(s, 14);
     // selection of the max_contact_points deepest survivors of the env (ties: lower broad-phase rank first, then the
     // scan order leg-major): MJX's sequential top-k picks exactly the pairs that fewer than max_contact_points others
@@ -930,7 +957,7 @@ struct QPhysics {
 #pragma unroll
         for (int i2 = 0; i2 < kMaxPenQ; i2++) {
           if (i2 >= ncol) continue;
-          const bool first = (cdist[j][i2] < d) | ((cdist[j][i2] == d) & ((crank[j][i2] < r) | ((crank[j][i2] == r) & (j * kMaxPenQ + i2 < ord))));
+          const bool first = (cdist[j][i2] < d) | ((cdist[j][i2] == d) & (((unsigned)crank[j][i2] < (unsigned)r) | ((crank[j][i2] == r) & (j * kMaxPenQ + i2 < ord))));
           beat += (ok[j][i2] & first) ? 1 : 0;
         }
       return okm & (beat < nslot);

@@ -1,0 +1,51 @@
+"""Find env-steps where the f64 oracle converged, the f32 oracle agrees with it, and the HIP step does NOT, and save
+their inputs for replay (tools/gpu_replay_case.py).    python tools/gpu_parity_cases.py out.npz [ctrl_dt]"""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_parity as P
+from oracle import oracle
+from phase_guided_terrain_traversal_amd import abi
+
+def find(task, n, terrain, steps, ctrl_dt):
+    env, hb, cs, ms = P.make_pair(task, n, terrain, ctrl_dt=ctrl_dt)
+    h64 = oracle.HostBuffers(n, with_variant="variant" in hb.arrays)
+    if "variant" in hb.arrays: h64["variant"][...] = hb["variant"]
+    env.reset(3); oracle.reset(cs, ms, terrain, hb, seed=3, nthreads=16)
+    rng = np.random.default_rng(1)
+    cases = []
+    for k in range(steps):
+        P.sync_to_host(env, hb, h64)
+        pre = {kk: hb[kk].copy() for kk in ("state", "istate", "scan_z", "done")}
+        act = np.tanh(rng.normal(size=(n, 12)) * 0.6).astype(np.float32)
+        env.step(torch.from_numpy(act).cuda())
+        r32, r64 = np.zeros(n), np.zeros(n)
+        oracle.step(cs, ms, terrain, hb, act, seed=3, nthreads=16, resid=r32)
+        oracle.step(cs, ms, terrain, h64, act, seed=3, nthreads=16, fp64=True, resid=r64)
+        torch.cuda.synchronize()
+        g = {kk: v.cpu().numpy() for kk, v in env.buffers.items()}
+        eg = P.per_env_errors(g, hb); ef = P.per_env_errors(hb.arrays, h64)
+        W = (r64 < 1e-6) & (ef["qpos"] < 1e-5) & (ef["qvel"] < 1e-3)
+        for e in np.nonzero(W & (eg["qpos"] > 1e-4))[0]:
+            cases.append(dict(step=k, env=e, state=pre["state"][:, e], istate=pre["istate"][:, e], scan_z=pre["scan_z"][e], action=act[e],
+                              variant=hb["variant"][e] if "variant" in hb.arrays else 0, gpu=g["state"][:55, e], o32=hb["state"][:55, e], o64=h64["state"][:55, e],
+                              ni=np.array([g["dbg_niter"][e], hb["dbg_niter"][e], h64["dbg_niter"][e]]), r=np.array([r32[e], r64[e]])))
+    env.close()
+    return cases
+
+if __name__ == "__main__":
+    A = os.path.join(ROOT, "phase_guided_terrain_traversal_amd", "assets", "terrains")
+    ctrl_dt = float(sys.argv[2]) if len(sys.argv) > 2 else 0.005
+    os.environ.setdefault("PGTT_LAYOUT", "hex")
+    out = {}
+    for name, task, terr in (("flat", "flat_terrain", None), ("level4", "stairs", np.load(os.path.join(A, "level4.npy")))):
+        cs = find(task, 512, terr, 60, ctrl_dt)
+        print(name, "violators in W:", len(cs))
+        for i, c in enumerate(cs):
+            print("  ", i, "step", c["step"], "env", c["env"], "ni", c["ni"], "r", c["r"], "err qpos", np.abs(c["gpu"][:19] - c["o32"][:19]).max(), "qvel", np.abs(c["gpu"][19:37] - c["o32"][19:37]).max())
+            for k, v in c.items(): out[f"{name}/{i}/{k}"] = np.asarray(v)
+        out[f"{name}/n"] = np.asarray(len(cs))
+    os.makedirs(os.path.dirname(os.path.abspath(sys.argv[1])), exist_ok=True)
+    np.savez_compressed(sys.argv[1], **out)
