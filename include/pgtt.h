@@ -254,6 +254,12 @@ int pgtt_physics(pgtt_handle h, const float* action_Nx12, void* stream);  /* 4 x
 int pgtt_observe(pgtt_handle h, const float* action_Nx12, void* stream);  /* scan + obs + rewards + bookkeeping */
 int pgtt_scan(pgtt_handle h, float yaw_override_or_nan, void* stream);     /* K11 alone -> scan_z */
 
+/* TEST HOOKS (off by default; tests/test_gpu_golden.py): the reference-generated fixtures of Joystick.step / Joystick.reset
+ * (go2/joystick_pgtt.py:50-131,141-231 executed with jax.random stubbed and fake physics outputs) can only be replayed when every
+ * uniform draw returns a fixed value (rng_value; NaN = the Philox streams) and when the step takes the 117 scan heights from
+ * buf.scan_z instead of casting rays (scan_preset != 0). */
+int pgtt_set_test_overrides(pgtt_handle h, float rng_value_or_nan, int scan_preset);
+
 /* enable = 0 off, 1 time every step, n > 1 time every n-th step (an event record costs a few us of GPU idle).
  * time of the most recent physics / observe kernels, measured with HIP events on `stream`
  * (valid after the stream is synchronised; used by bench.py for the roofline figure). */

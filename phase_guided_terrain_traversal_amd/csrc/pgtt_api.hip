@@ -46,6 +46,7 @@ struct pgtt_env {
   bool bound = false;
   unsigned long long seed = 0;
   long long env_off = 0;
+  float test_rng_fix = NAN; int test_scan_preset = 0;   // pgtt_set_test_overrides
   bool timing = false;
   int timing_period = 1, timing_tick = 0; bool timing_now = false;   // time every timing_period-th step (event records cost ~3 us of GPU idle each)
   bool split_observe = false;     // observe = observe_kernel<OBS_STEP_OBS> + task_kernel (PGTT_OBSERVE=split|fused forces)
@@ -80,6 +81,7 @@ pgtt::KArgs make_args(pgtt_env* h, const unsigned char* mask, float yaw_override
   pgtt::KArgs a;
   a.model = h->d_model; a.cfg = h->d_cfg; a.terrain = h->d_terrain; a.T = h->T; a.B = h->B;
   a.buf = h->buf; a.N = h->N; a.seed = h->seed; a.env_off = h->env_off; a.mask = mask; a.yaw_override = yaw_override; a.write_qpos = 0;
+  a.rng_fix = h->test_rng_fix; a.scan_preset = h->test_scan_preset;
 #if defined(PGTT_TRACE) || defined(PGTT_TIME)
   a.trace = pgtt_trace_buffer();
 #endif
@@ -315,6 +317,12 @@ int pgtt_scan(pgtt_handle h, float yaw_override_or_nan, void* stream) {
   pgtt::KArgs a = make_args(h, nullptr, yaw_override_or_nan);
   launch_observe<pgtt::OBS_SCAN_ONLY>(h, a, nullptr, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
+  return PGTT_OK;
+}
+
+int pgtt_set_test_overrides(pgtt_handle h, float rng_value_or_nan, int scan_preset) {
+  if (!h) return fail(PGTT_E_ARG, "null handle");
+  h->test_rng_fix = rng_value_or_nan; h->test_scan_preset = scan_preset != 0;
   return PGTT_OK;
 }
 

@@ -27,6 +27,12 @@ struct KArgs {
   const unsigned char* mask;
   float yaw_override;          // NaN = use the base yaw
   int write_qpos;              // MODE_FORWARD: store the (quaternion-normalised) qpos
+  // test hooks (pgtt_set_test_overrides; both off in normal operation): with rng_fix != NaN every uniform draw returns rng_fix
+  // (the reference-generated fixtures tests/golden/task_*.npz were produced with jax.random stubbed that way), and with
+  // scan_preset != 0 the step's observe kernel takes the 117 scan heights from buf.scan_z instead of casting rays (the
+  // fixtures hold scan values, not terrains)
+  float rng_fix;
+  int scan_preset;
 #if defined(PGTT_TRACE) || defined(PGTT_TIME)
   float* trace;                // debugging builds only: per-iteration solver record of env 0
 #endif
@@ -49,8 +55,12 @@ PG_INL float rng_uniform(unsigned long long seed, unsigned env, unsigned epoch, 
   unsigned w = (idx & 3) == 0 ? c0 : ((idx & 3) == 1 ? c1 : ((idx & 3) == 2 ? c2 : c3));
   return (float)(w >> 8) * (1.0f / 16777216.0f);
 }
-PG_INL int exp_timer(unsigned long long seed, unsigned env, unsigned epoch, unsigned stream, float ctrl_dt) {
-  double u = (double)rng_uniform(seed, env, epoch, stream, 0);
+PG_INL float rng_uniform(unsigned long long seed, unsigned env, unsigned epoch, unsigned stream, int idx, float fix) {
+  const float u = rng_uniform(seed, env, epoch, stream, idx);
+  return fix == fix ? fix : u;
+}
+PG_INL int exp_timer(unsigned long long seed, unsigned env, unsigned epoch, unsigned stream, float ctrl_dt, float fix) {
+  double u = (double)rng_uniform(seed, env, epoch, stream, 0, fix);
   double t = -log1p(-u) * 5.0;
   return (int)rint(t / (double)ctrl_dt);
 }
@@ -302,9 +312,9 @@ __global__ __launch_bounds__(64) void reset_pose_kernel(KArgs a) {
   float qpos[19];
 #pragma unroll
   for (int i = 0; i < 19; i++) qpos[i] = m->key_qpos[i];
-  qpos[0] += rng_uniform(a.seed, id, ep, PGTT_RS_RESET_XY, 0) * 1.0f + -0.5f;
-  qpos[1] += rng_uniform(a.seed, id, ep, PGTT_RS_RESET_XY, 1) * 1.0f + -0.5f;
-  float yaw = rng_uniform(a.seed, id, ep, PGTT_RS_RESET_YAW, 0) * 6.28f + -3.14f;
+  qpos[0] += rng_uniform(a.seed, id, ep, PGTT_RS_RESET_XY, 0, a.rng_fix) * 1.0f + -0.5f;
+  qpos[1] += rng_uniform(a.seed, id, ep, PGTT_RS_RESET_XY, 1, a.rng_fix) * 1.0f + -0.5f;
+  float yaw = rng_uniform(a.seed, id, ep, PGTT_RS_RESET_YAW, 0, a.rng_fix) * 6.28f + -3.14f;
   float sn, cs; sincosf(0.5f * yaw, &sn, &cs);
   Q4 q = qmul(Q4{qpos[3], qpos[4], qpos[5], qpos[6]}, Q4{cs, 0.f * sn, 0.f * sn, 1.f * sn});
   qpos[3] = q.w; qpos[4] = q.x; qpos[5] = q.y; qpos[6] = q.z;
@@ -312,7 +322,7 @@ __global__ __launch_bounds__(64) void reset_pose_kernel(KArgs a) {
   for (int i = 0; i < 19; i++) S[(PGTT_S_QPOS + i) * (long)N + e] = qpos[i];
 #pragma unroll
   for (int i = 0; i < 18; i++) {
-    S[(PGTT_S_QVEL + i) * (long)N + e] = i < 6 ? rng_uniform(a.seed, id, ep, PGTT_RS_RESET_VEL, i) * 0.2f + -0.1f : 0.f;
+    S[(PGTT_S_QVEL + i) * (long)N + e] = i < 6 ? rng_uniform(a.seed, id, ep, PGTT_RS_RESET_VEL, i, a.rng_fix) * 0.2f + -0.1f : 0.f;
     S[(PGTT_S_QWARM + i) * (long)N + e] = 0.f;
   }
 }
@@ -413,7 +423,7 @@ PG_INL float quad4_min(float x) { x = fminf(x, dpp_f<0xB1>(x)); x = fminf(x, dpp
 template <bool WAVE>
 PG_INL void task_rewards(const float* sh_st, const float* sh_fr, const float* sh_act, const PgttConfig* __restrict__ cfg,
                          const PgttModel* __restrict__ m, bool baseline, unsigned long long seed, unsigned id, unsigned ep, float dt,
-                         TaskScalars& t) {
+                         float rng_fix, TaskScalars& t) {
   float (&cmd)[3] = t.cmd; float (&phase)[4] = t.phase; float (&air)[4] = t.air; float (&peak)[4] = t.peak; float (&hmax)[4] = t.hmax;
   float (&last_contact)[4] = t.last_contact; float (&contact)[4] = t.contact; float (&first_contact)[4] = t.first_contact;
   float (&metrics)[PGTT_NMETRIC] = t.metrics;
@@ -509,13 +519,13 @@ PG_INL void task_rewards(const float* sh_st, const float* sh_fr, const float* sh
     if (timer <= 0) {
 #pragma unroll
       for (int i = 0; i < 3; i++) {
-        float y = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_Y, i) * (cfg->cmd_u_max[i] - cfg->cmd_u_min[i]) + cfg->cmd_u_min[i];
-        float zb = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_Z, i) < cfg->cmd_b[i] ? 1.f : 0.f;
-        float wb = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_W, i) < 0.5f ? 1.f : 0.f;
+        float y = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_Y, i, rng_fix) * (cfg->cmd_u_max[i] - cfg->cmd_u_min[i]) + cfg->cmd_u_min[i];
+        float zb = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_Z, i, rng_fix) < cfg->cmd_b[i] ? 1.f : 0.f;
+        float wb = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_W, i, rng_fix) < 0.5f ? 1.f : 0.f;
         cmd[i] = cmd[i] - wb * (cmd[i] - y * zb);
       }
     }
-    if (done || timer <= 0) timer = exp_timer(a.seed, id, ep, PGTT_RS_TIMER, dt);
+    if (done || timer <= 0) timer = exp_timer(a.seed, id, ep, PGTT_RS_TIMER, dt, rng_fix);
     float sp = 0.f;
 #pragma unroll
     for (int f = 0; f < 4; f++) {
@@ -631,6 +641,7 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
     float dist = hit[h] == INFINITY ? -1.0f : hit[h];
     z[h] = org[h].z + (-1.0f) * dist;
     int idx = lane + 64 * h;
+    if ((OMODE == OBS_STEP || OMODE == OBS_STEP_OBS) && a.scan_preset) z[h] = a.buf.scan_z[(long)e * PGTT_NSCAN + (idx < PGTT_NSCAN ? idx : 0)];   // test hook
     if (idx < PGTT_NSCAN) { sh_scan[idx] = z[h]; a.buf.scan_z[(long)e * PGTT_NSCAN + idx] = z[h]; }
   }
   if (OMODE == OBS_SCAN_ONLY) return;
@@ -678,13 +689,13 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
   if (OMODE == OBS_RESET) {
 #pragma unroll
     for (int i = 0; i < 3; i++)
-      cmd[i] = rng_uniform(a.seed, id, ep, PGTT_RS_RESET_CMD, i) * (cfg->cmd_u_max[i] - cfg->cmd_u_min[i]) + cfg->cmd_u_min[i];
-    gait_freq = rng_uniform(a.seed, id, ep, PGTT_RS_RESET_FREQ, 0) * (cfg->gait_freq[1] - cfg->gait_freq[0]) + cfg->gait_freq[0];
+      cmd[i] = rng_uniform(a.seed, id, ep, PGTT_RS_RESET_CMD, i, a.rng_fix) * (cfg->cmd_u_max[i] - cfg->cmd_u_min[i]) + cfg->cmd_u_min[i];
+    gait_freq = rng_uniform(a.seed, id, ep, PGTT_RS_RESET_FREQ, 0, a.rng_fix) * (cfg->gait_freq[1] - cfg->gait_freq[0]) + cfg->gait_freq[0];
     phase_dt = (float)(2 * M_PI) * dt * gait_freq;
     phase[0] = 0.f; phase[1] = (float)M_PI; phase[2] = (float)M_PI; phase[3] = 0.f;
 #pragma unroll
     for (int f = 0; f < 4; f++) { air[f] = 0.f; peak[f] = 0.f; hmax[f] = 0.1f; hmin[f] = 0.f; last_contact[f] = 0.f; contact[f] = 0.f; first_contact[f] = 0.f; }
-    timer = exp_timer(a.seed, id, ep, PGTT_RS_RESET_TIMER, dt);
+    timer = exp_timer(a.seed, id, ep, PGTT_RS_RESET_TIMER, dt, a.rng_fix);
     step_ctr = 0; ep_steps = 0;
     __syncthreads();
     // info arrays that _get_obs reads
@@ -742,7 +753,8 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
     else if (i == 38 + PGTT_NSCAN) base = gait_freq;
     else if (i < 39 + PGTT_NSCAN + 12) base = sh_st[PGTT_S_LAST_ACT + i - (39 + PGTT_NSCAN)];
     else base = sel4(i - (51 + PGTT_NSCAN), cmd[0], cmd[1], cmd[2], 0.f);
-    const float u = (float)(sh_rng[4 * rblk + sidx] >> 8) * (1.0f / 16777216.0f);      // word sidx & 3 of block rblk + (sidx >> 2)
+    const float uw = (float)(sh_rng[4 * rblk + sidx] >> 8) * (1.0f / 16777216.0f);     // word sidx & 3 of block rblk + (sidx >> 2)
+    const float u = a.rng_fix == a.rng_fix ? a.rng_fix : uw;
     const float noisy = scale != 0.f ? base + (2.f * u - 1.f) * lvl * scale : base;
     const float v = offs != 0.f ? noisy - offs : noisy;
     sh_obs[io] = v;
@@ -795,7 +807,7 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
 #pragma unroll
     for (int f = 0; f < 4; f++) { t.phase[f] = phase[f]; t.air[f] = air[f]; t.peak[f] = peak[f]; t.hmax[f] = hmax[f]; t.last_contact[f] = last_contact[f]; t.contact[f] = contact[f]; t.first_contact[f] = first_contact[f]; }
     t.phase_dt = phase_dt; t.step_ctr = step_ctr; t.timer = timer;
-    task_rewards<true>(sh_st, sh_fr, sh_act, cfg, m, baseline, a.seed, id, ep, dt, t);
+    task_rewards<true>(sh_st, sh_fr, sh_act, cfg, m, baseline, a.seed, id, ep, dt, a.rng_fix, t);
 #pragma unroll
     for (int i = 0; i < 3; i++) cmd[i] = t.cmd[i];
 #pragma unroll
@@ -940,7 +952,7 @@ __global__ __launch_bounds__(64) void task_kernel(KArgs a, const float* __restri
     hist_v[i] = upd ? nv : st[PGTT_S_QVEL_HIST + i];
     hist_q[i] = upd ? nq : st[PGTT_S_QERR_HIST + i];
   }
-  task_rewards<false>(st, fr, act, cfg, m, baseline, a.seed, id, ep, dt, t);
+  task_rewards<false>(st, fr, act, cfg, m, baseline, a.seed, id, ep, dt, a.rng_fix, t);
   // Episode / AutoReset wrapper semantics
   bool wdone = t.done;
   if (cfg->autoreset) {

@@ -143,6 +143,10 @@ class Joystick:
         native.check(self._lib.pgtt_scan(self._h, float("nan") if yaw is None else float(yaw), self._stream()))
         return self.buffers["scan_z"]
 
+    def set_test_overrides(self, rng_value: Optional[float] = None, scan_preset: bool = False) -> None:
+        """test hooks of libpgtt (include/pgtt.h): fixed uniform draws / scan heights taken from buffers['scan_z']"""
+        native.check(self._lib.pgtt_set_test_overrides(self._h, float("nan") if rng_value is None else float(rng_value), int(scan_preset)))
+
     def enable_timing(self, on=True) -> None:
         """False / True / n > 1 = time every n-th step (HIP events around the kernels, on the launch stream)"""
         native.check(self._lib.pgtt_enable_timing(self._h, int(on)))
