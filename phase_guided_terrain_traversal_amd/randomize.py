@@ -14,7 +14,8 @@ Distributions are the reference's, including its quirks:
   * body masses scale by U(0.9, 1.1) (all bodies) and the base gets an extra U(-1, 1) kg, inertias are NOT
     rescaled; frictionloss is nominally 0 so its scaling is a no-op;
   * gainprm[:,0] and biasprm[:,1] share one U(0.9, 1.1) factor per actuator.
-Streams: numpy Philox keyed by (seed, global env id) so a shard draws the same numbers as the full batch
+Streams: ONE numpy Philox stream per seed in which env e owns a fixed block of 280 outputs (vectorised: no per-env Python
+loop), so a shard draws the same numbers as the full batch
 (JAX threefry equivalence is not required).
 """
 from __future__ import annotations
@@ -26,6 +27,20 @@ import numpy as np
 from . import abi
 
 
+# layout of one env's block of uniform draws (fixed width, whatever the task / terrain: a shard then finds its envs' blocks by
+# env id alone).  280 doubles = 70 Philox4x64 counter steps per env.
+_D_FLOOR, _D_BOXF, _D_FLOSS, _D_ARM, _D_IPOS, _D_MASS, _D_BASEM, _D_QPOS0, _D_DAMP, _D_GAIN, _D_VAR = 0, 1, 101, 113, 125, 128, 242, 243, 255, 267, 279
+_DRAWS = 280
+
+
+def _uniform_blocks(seed: int, first_env: int, n: int) -> np.ndarray:
+    """[n, 280] uniforms in [0, 1): ONE Philox4x64 stream keyed by the seed, env e owns outputs [280 e, 280 (e + 1)) - vectorised
+    (no per-env generator objects: 32 768 envs take about a second instead of a Python loop of 32 768 generators) and independent of how the envs are sharded"""
+    bg = np.random.Philox(key=[int(seed), 0x5047_5454])
+    bg.advance(int(first_env) * (_DRAWS // 4))
+    return np.random.Generator(bg).random((n, _DRAWS))
+
+
 def domain_randomize(model: Dict[str, Any], num_envs: int, seed: int = 0, terrain: Optional[np.ndarray] = None,
                      env_id_offset: int = 0, enable: bool = True, _frac: Optional[float] = None) -> Dict[str, np.ndarray]:
     """`_frac` (tests only): every draw returns lo + _frac * (hi - lo) instead of a Philox sample, which is how
@@ -34,46 +49,38 @@ def domain_randomize(model: Dict[str, Any], num_envs: int, seed: int = 0, terrai
     P = np.zeros((abi.NPARAM, n), dtype=np.float32)
     nbox = 0 if terrain is None else terrain.shape[1]
     T = 0 if terrain is None else terrain.shape[0]
-    variant = np.zeros(n, dtype=np.int32)
-    box_friction = np.full((abi.MAX_BOX, n), float(model["box_friction"][0]), dtype=np.float32) if nbox else None
-    mass0 = np.asarray(model["body_mass"], dtype=np.float64)
-    for e in range(n):
-        g = np.random.Generator(np.random.Philox(key=[int(seed), int(env_id_offset + e)]))
-        if _frac is None:
-            u = lambda lo, hi, size=None: g.uniform(lo, hi, size)
-        else:
-            u = lambda lo, hi, size=None: (lo + _frac * (hi - lo)) * (np.ones(size) if size is not None else 1.0)
-        floor_fr = u(0.4, 1.0)                                   # drawn in both variants
-        if nbox:
-            bf = u(0.4, 1.0, nbox)
-            floor_fr = float(model["floor_friction"][0])         # dead draw on the stairs task
-        _ = u(0.9, 1.1, 12)                                      # frictionloss scale (nominal 0 => no-op)
-        armature = np.asarray(model["dof_armature"][6:]) * u(1.0, 1.05, 12)
-        dpos = u(-0.05, 0.05, 3)
-        # randomize.py draws for model.nbody bodies (world + robot + boxes); only the 13 robot bodies matter
-        dmass = u(0.9, 1.1, 14 + nbox)[1:14]
-        mass = mass0 * dmass
-        mass[0] += u(-1.0, 1.0)
-        qpos0 = np.asarray(model["qpos0"][7:]) + u(-0.05, 0.05, 12)
-        damping = np.asarray(model["dof_damping"][6:]) * u(0.9, 1.1, 12)
-        dgain = u(0.9, 1.1, 12)
-        if not enable:
-            armature, dpos, mass = np.asarray(model["dof_armature"][6:]), np.zeros(3), mass0.copy()
-            qpos0, damping, dgain = np.asarray(model["qpos0"][7:]), np.asarray(model["dof_damping"][6:]), np.ones(12)
-            floor_fr = float(model["floor_friction"][0])
-        P[abi.P_BODY_MASS:abi.P_BODY_MASS + 13, e] = mass
-        P[abi.P_BASE_IPOS:abi.P_BASE_IPOS + 3, e] = np.asarray(model["body_ipos"][0]) + dpos
-        P[abi.P_QPOS0:abi.P_QPOS0 + 12, e] = qpos0
-        P[abi.P_ARMATURE:abi.P_ARMATURE + 12, e] = armature
-        P[abi.P_DAMPING:abi.P_DAMPING + 12, e] = damping
-        P[abi.P_GAIN:abi.P_GAIN + 12, e] = np.asarray(model["act_gain"]) * dgain
-        P[abi.P_BIAS1:abi.P_BIAS1 + 12, e] = np.asarray(model["act_bias"])[:, 1] * dgain
-        P[abi.P_FLOOR_FRICTION, e] = floor_fr
-        if nbox:
-            variant[e] = int(g.integers(0, T)) if _frac is None else int(_frac * (T - 1))
-            if enable:
-                box_friction[:nbox, e] = bf
-    out = {"params": P, "variant": variant}
+    U = _uniform_blocks(seed, env_id_offset, n) if _frac is None else np.full((n, _DRAWS), float(_frac))
+    u = lambda lo, hi, col, width=1: lo + U[:, col:col + width] * (hi - lo)         # [n, width]
+    nominal_floor = float(model["floor_friction"][0])
+    # stairs: the floor-friction draw is dead code in the reference (randomize.py:30-36), the plane keeps its nominal value
+    floor_fr = np.full(n, nominal_floor) if nbox else u(0.4, 1.0, _D_FLOOR)[:, 0]
+    armature = np.asarray(model["dof_armature"][6:])[None] * u(1.0, 1.05, _D_ARM, 12)      # frictionloss (_D_FLOSS): nominal 0, scaling is a no-op
+    dpos = u(-0.05, 0.05, _D_IPOS, 3)
+    # randomize.py scales model.nbody masses (world + robot + boxes); only the 13 robot bodies matter: draws 1..13 of the block
+    mass = np.asarray(model["body_mass"], dtype=np.float64)[None] * u(0.9, 1.1, _D_MASS + 1, 13)
+    mass[:, 0] += u(-1.0, 1.0, _D_BASEM)[:, 0]
+    qpos0 = np.asarray(model["qpos0"][7:])[None] + u(-0.05, 0.05, _D_QPOS0, 12)
+    damping = np.asarray(model["dof_damping"][6:])[None] * u(0.9, 1.1, _D_DAMP, 12)
+    dgain = u(0.9, 1.1, _D_GAIN, 12)
+    if not enable:
+        armature = np.repeat(np.asarray(model["dof_armature"][6:])[None], n, 0); dpos = np.zeros((n, 3))
+        mass = np.repeat(np.asarray(model["body_mass"], dtype=np.float64)[None], n, 0)
+        qpos0 = np.repeat(np.asarray(model["qpos0"][7:])[None], n, 0); damping = np.repeat(np.asarray(model["dof_damping"][6:])[None], n, 0)
+        dgain = np.ones((n, 12)); floor_fr = np.full(n, nominal_floor)
+    P[abi.P_BODY_MASS:abi.P_BODY_MASS + 13] = mass.T
+    P[abi.P_BASE_IPOS:abi.P_BASE_IPOS + 3] = (np.asarray(model["body_ipos"][0])[None] + dpos).T
+    P[abi.P_QPOS0:abi.P_QPOS0 + 12] = qpos0.T
+    P[abi.P_ARMATURE:abi.P_ARMATURE + 12] = armature.T
+    P[abi.P_DAMPING:abi.P_DAMPING + 12] = damping.T
+    P[abi.P_GAIN:abi.P_GAIN + 12] = (np.asarray(model["act_gain"])[None] * dgain).T
+    P[abi.P_BIAS1:abi.P_BIAS1 + 12] = (np.asarray(model["act_bias"])[:, 1][None] * dgain).T
+    P[abi.P_FLOOR_FRICTION] = floor_fr
+    out = {"params": P, "variant": np.zeros(n, dtype=np.int32)}
     if nbox:
-        out["box_friction"] = box_friction
+        # randint(0, T) (randomize.py:97-100); the recorded fixture pins it to int(f (T - 1))
+        out["variant"] = (np.minimum((U[:, _D_VAR] * T).astype(np.int64), T - 1) if _frac is None else np.full(n, int(_frac * (T - 1)))).astype(np.int32)
+        bf = np.full((abi.MAX_BOX, n), float(model["box_friction"][0]), dtype=np.float32)
+        if enable:
+            bf[:nbox] = u(0.4, 1.0, _D_BOXF, nbox).T
+        out["box_friction"] = bf
     return out

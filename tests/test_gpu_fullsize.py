@@ -220,3 +220,62 @@ def test_scan_on_tilted_boxes_matches_the_oracle():
         worst = max(worst, float(np.median(d)))
     assert worst < 1e-5
     env.close()
+
+
+def test_configs3_wfc_dr_8192_full_size():
+    """BASELINE configs[3] at its full size: 8192 envs (the batch size at which the launcher switches to the quad lane layout),
+    WFC-generated terrain + full randomize.py DR.  Size-independent properties: bitwise run-to-run determinism, two
+    4096-env shards == one batch (DR and RNG streams are keyed by the global env id), finiteness along a rollout with
+    AutoReset, scan == analytic box tops of the env's own variant."""
+    from phase_guided_terrain_traversal_amd.env import Joystick
+    from phase_guided_terrain_traversal_amd.randomize import domain_randomize
+    from phase_guided_terrain_traversal_amd.terrain_gen import create_random_matrix
+    n = 8192
+    terrain = create_random_matrix(100, 100, 5, 0.05, 0.13, seed=3)
+    model = mjcf.load_model("stairs")
+
+    def build(cnt, off):
+        out = domain_randomize(model, cnt, seed=3, terrain=terrain, env_id_offset=off)
+        return Joystick("stairs", configs.training_config(), num_envs=cnt, terrain=terrain, device="cuda:0", autoreset=True, env_id_offset=off,
+                        variant=torch.from_numpy(out["variant"]), params=torch.from_numpy(out["params"]), box_friction=torch.from_numpy(out["box_friction"])), out
+
+    def acts(k, cnt, off):
+        g = np.random.Generator(np.random.Philox(key=[9, k]))
+        return torch.from_numpy(np.tanh(g.normal(size=(n, 12)) * 0.6).astype(np.float32)[off:off + cnt]).cuda()
+
+    os.environ["PGTT_LAYOUT"] = "quad"          # the shards must run the layout the full batch selects by itself
+    try:
+        h0, _ = build(n // 2, 0); h1, _ = build(n // 2, n // 2)
+    finally:
+        del os.environ["PGTT_LAYOUT"]
+    a, dr = build(n, 0); b, _ = build(n, 0)
+    for e in (a, b, h0, h1):
+        e.reset(seed=5)
+    for k in range(40):
+        a.step(acts(k, n, 0)); b.step(acts(k, n, 0)); h0.step(acts(k, n // 2, 0)); h1.step(acts(k, n // 2, n // 2))
+    sa, sb, s0, s1 = snapshot(a), snapshot(b), snapshot(h0), snapshot(h1)
+    for key in ("state", "istate", "obs_state", "obs_priv", "reward", "done", "metrics", "scan_z", "frame"):
+        assert torch.equal(sa[key], sb[key]), key
+        merged = torch.cat([s0[key], s1[key]], 0 if (sa[key].dim() == 1 or sa[key].shape[0] == n) else 1)
+        assert torch.equal(sa[key], merged), key
+        assert torch.isfinite(sa[key].float()).all(), key
+    assert float(sa["done"].sum()) >= 0 and int(sa["istate"][abi.I_STEP].min()) == 40
+    # scan of the last step against the analytic tops of each env's own variant
+    S = sa["state"].cpu().numpy(); z = sa["scan_z"].cpu().numpy(); variant = dr["variant"]
+    q = S[3:7]; yaw = np.arctan2(2 * (q[0] * q[3] + q[1] * q[2]), 1 - 2 * (q[2] ** 2 + q[3] ** 2))
+    r, c = np.meshgrid(np.arange(13), np.arange(9), indexing="ij")
+    ox, oy = ((6 - r) * 0.1).ravel(), ((4 - c) * 0.1).ravel()
+    bad = 0
+    done_now = sa["done"].cpu().numpy() != 0          # a finished episode's qpos was replaced by the first state after the scan
+    for e in range(0, n, 61):
+        if done_now[e]:
+            continue
+        px = S[0, e] + ox * np.cos(yaw[e]) - oy * np.sin(yaw[e]); py = S[1, e] + ox * np.sin(yaw[e]) + oy * np.cos(yaw[e])
+        edge = np.abs(z[e] - _tops(terrain[variant[e]], np.stack([px, py], 1))) > 1e-4
+        if edge.any():
+            for dx, dy in ((2e-4, 0), (-2e-4, 0), (0, 2e-4), (0, -2e-4)):
+                edge &= np.abs(z[e] - _tops(terrain[variant[e]], np.stack([px + dx, py + dy], 1))) > 1e-4
+        bad += int(edge.sum())
+    assert bad == 0
+    for e in (a, b, h0, h1):
+        e.close()

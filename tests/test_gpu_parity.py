@@ -220,6 +220,17 @@ def test_level13_dr_autoreset_parity(layout):
     run_parity("stairs", 128, terrain, steps=40, dr=True, autoreset=True)
 
 
+def test_wfc_terrain_full_dr_parity(layout):
+    """BASELINE configs[3] through the parity bar: terrain GENERATED on the host by the wave-function-collapse pipeline
+    (terrain_gen.create_random_matrix = terrain/generator.py:368-391 + getIndexes.py:28-79 + wfc) and the full randomize.py DR
+    (go2/randomize.py:23-171), with the AutoReset wrapper on, both lane layouts (8192 envs run the quad layout)"""
+    from phase_guided_terrain_traversal_amd.terrain_gen import create_random_matrix
+    terrain = create_random_matrix(100, 100, 5, 0.05, 0.13, seed=3)
+    assert terrain.shape == (100, 100, 10) and terrain.dtype == np.float32
+    st = run_parity("stairs", 192, terrain, steps=30, dr=True, autoreset=True)
+    assert st["box_contacts"] > 1000
+
+
 @pytest.mark.parametrize("level", ["1", "2", "3", "7", "10", "05", "09"])
 def test_curriculum_levels_parity(level):
     """the remaining level files of the reference's training curriculum (BASELINE configs[4]; level4 and level13 are covered
