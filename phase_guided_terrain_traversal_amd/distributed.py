@@ -24,12 +24,14 @@ def shard_range(num_envs_total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """(rank, local_rank, world) from the torchrun environment; initialises the process group when world > 1."""
+def init_from_env(backend: Optional[str] = None, force: bool = False) -> Tuple[int, int, int]:
+    """(rank, local_rank, world) from the torchrun environment; initialises the process group when world > 1 (or when
+    `force` is set: a one-rank group still routes the collective through RCCL, which is how the single-GPU test box
+    exercises the library)."""
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
@@ -68,7 +70,7 @@ class MetricReducer:
         buf = self.acc.clone()
         buf[abi.NMETRIC + 2] += self.count
         self.count = 0.0
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized():
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         self.acc.zero_()
         n = buf[abi.NMETRIC + 2].clamp(min=1.0)

@@ -6,10 +6,11 @@
     (512, 256, 128) with swish, policy obs key "state" (171), value obs key "privileged_state" (215).
 
 Brax defaults it relies on [UPSTREAM-RECALL]: tanh-normal action distribution with scale = softplus(raw) + 1e-3,
-clipping_epsilon 0.3, gae_lambda 0.95, normalize_advantage, value loss 0.5 * 0.5 * mse, bootstrap on truncation
-with V(next_obs).  This is the CALLER of the hot path (out of the §8 a-e scope); it exists so that env-steps/s can be
+clipping_epsilon 0.3, gae_lambda 0.95, normalize_advantage (population std), value loss 0.5 * 0.5 * mse, compute_gae with
+zeroed temporal-difference error and carry at truncated steps.  This is the CALLER of the hot path (out of the §8 a-e scope); it exists so that env-steps/s can be
 measured inside a real training loop and `train.py` keeps the reference's CLI.  Dense layers are plain library GEMMs
-(torch -> hipBLASLt); nothing here is a custom kernel.
+(torch -> hipBLASLt); two launch-bound pieces of the update are hand-written HIP in csrc/pgtt_ppo.hip (the fused policy
+loss with its gradient, and the split-K fp32-MFMA weight / bias gradient of the Linear layers over the long minibatch).
 """
 from __future__ import annotations
 
@@ -27,7 +28,7 @@ from . import abi
 
 
 class RunningNorm:
-    """Welford running mean/std per observation key (brax running_statistics), count starts at 0, std floor 1e-6."""
+    """Welford running mean/std per observation key (brax running_statistics): count starts at 0 with std = 1, std floor 1e-6."""
 
     def __init__(self, dim: int, device):
         self.count = torch.zeros((), device=device, dtype=torch.float64)
@@ -54,7 +55,10 @@ class RunningNorm:
     @property
     def std(self) -> torch.Tensor:
         var = self.m2 / self.count.clamp(min=1.0).to(self.m2.dtype)        # device-only: usable inside a captured graph
-        return torch.sqrt(torch.clamp(var, min=1e-12)).clamp(min=1e-6)
+        std = torch.sqrt(torch.clamp(var, min=1e-12)).clamp(min=1e-6)
+        # brax running_statistics.init_state: std = 1 before the first update (graph warm-up and the first rollout would
+        # otherwise feed obs * 1e6 to the policy)
+        return torch.where(self.count > 0, std, torch.ones_like(std))
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         return (x - self.mean) / self.std
@@ -261,7 +265,7 @@ class _Learner:
         B, idx, cfg, model = self.B, self.idx, self.cfg, self.model
         out = model.policy(self.norm_s(B["obs"][idx]))
         a = B["adv"][idx]
-        a = (a - a.mean()) / (a.std() + 1e-8)
+        a = (a - a.mean()) / (a.std(unbiased=False) + 1e-8)        # jnp.std: population standard deviation
         eps = torch.randn(out.shape[0], out.shape[1] // 2, dtype=out.dtype, device=out.device)
         return _FusedPolicyLoss.apply(out, B["u"][idx], B["logp"][idx], a, eps, float(cfg.clipping_epsilon), float(cfg.entropy_cost))
 
@@ -270,7 +274,7 @@ class _Learner:
         loc, scale = model.dist(self.norm_s(B["obs"][idx]))
         logp = model.log_prob(loc, scale, B["u"][idx])
         a = B["adv"][idx]
-        a = (a - a.mean()) / (a.std() + 1e-8)
+        a = (a - a.mean()) / (a.std(unbiased=False) + 1e-8)        # jnp.std: population standard deviation
         ratio = torch.exp(logp - B["logp"][idx])
         pol = -torch.min(ratio * a, torch.clamp(ratio, 1 - cfg.clipping_epsilon, 1 + cfg.clipping_epsilon) * a).mean()
         ent = model.entropy(loc, scale, loc + scale * torch.randn_like(loc)).mean()
@@ -368,16 +372,12 @@ def train(env, cfg: PPOConfig, progress_fn: Optional[Callable[[int, Dict[str, fl
             last_priv = obs["privileged_state"].clone()
             norm_s.update(batch["obs"]); norm_p.update(batch["priv"])
             values = model.value(norm_p(torch.cat([batch["priv"], last_priv[None]], 0))).squeeze(-1)     # [T+1, N]
-            # with AutoReset the obs after a done is the first obs of the env: V(next) at a truncation is V(first obs),
-            # exactly as in brax's acting loop (Transition.next_observation = nstate.obs)
-            term = batch["done"] * (1.0 - batch["trunc"])
-            nonterm = 1.0 - term
-            delta = batch["rew"] + cfg.discounting * values[1:] * nonterm - values[:-1]            # all T rows at once
-            carry = cfg.discounting * cfg.gae_lambda * nonterm * (1.0 - batch["done"])
-            adv = torch.empty_like(delta); last = torch.zeros(n, device=dev)
-            for t in reversed(range(T)):
-                last = torch.addcmul(delta[t], carry[t], last, out=adv[t])                          # one launch per row
-            ret = adv + values[:-1]
+            # brax.training.agents.ppo.losses.compute_gae [UPSTREAM-RECALL]: termination = done * (1 - truncation); a TRUNCATED
+            # step contributes no temporal-difference error and stops the backward recursion (the next observation belongs
+            # to the next episode after AutoReset, its value is not a bootstrap for this one), a terminated step bootstraps with
+            # 0; value targets vs = acc + V, advantages = (r + gamma (1 - term) vs[t+1] - V) (1 - trunc) with vs[T] = V(last obs)
+            adv, ret = compute_gae(batch["trunc"], batch["done"] * (1.0 - batch["trunc"]), batch["rew"], values[:-1], values[-1],
+                                   cfg.gae_lambda, cfg.discounting)
         torch.cuda.synchronize(dev); t1 = time.perf_counter(); t_env += t1 - t0
         flat = lambda x: x.reshape(T * n, *x.shape[2:])
         if learner is None:
@@ -409,6 +409,41 @@ def train(env, cfg: PPOConfig, progress_fn: Optional[Callable[[int, Dict[str, fl
     return model, (norm_s, norm_p), history
 
 
+def compute_gae(truncation: torch.Tensor, termination: torch.Tensor, rewards: torch.Tensor, values: torch.Tensor, bootstrap_value: torch.Tensor,
+                lambda_: float, discount: float):
+    """Generalised advantage estimation exactly as Brax's PPO computes it (brax/training/agents/ppo/losses.py compute_gae,
+    [UPSTREAM-RECALL]); all inputs [T, N] except bootstrap_value [N].  Returns (advantages, value targets vs)."""
+    mask = 1.0 - truncation
+    nonterm = 1.0 - termination
+    v_next = torch.cat([values[1:], bootstrap_value[None]], 0)
+    deltas = (rewards + discount * nonterm * v_next - values) * mask
+    carry = discount * lambda_ * nonterm * mask
+    acc = torch.empty_like(deltas); last = torch.zeros_like(bootstrap_value)
+    for t in reversed(range(deltas.shape[0])):
+        last = torch.addcmul(deltas[t], carry[t], last, out=acc[t])                             # one launch per row
+    vs = acc + values
+    vs_next = torch.cat([vs[1:], bootstrap_value[None]], 0)
+    adv = (rewards + discount * nonterm * vs_next - values) * mask
+    return adv, vs
+
+
 def checkpoint(model, norm_s, norm_p) -> Dict:
     st = lambda nm: {"count": nm.count.clone(), "mean": nm.mean.clone(), "m2": nm.m2.clone()}
     return {"model": {k: v.detach().clone() for k, v in model.state_dict().items()}, "norm_state": st(norm_s), "norm_priv": st(norm_p)}
+
+
+def export_policy_npz(ckpt: Dict, path: str) -> None:
+    """Write a checkpoint of `train` in the layout `policy.PolicyMLP` / tools/rollout_policy.py load - the role of the pickled
+    `policy{index}` file the reference writes next to each Orbax checkpoint (training/train.py:189-195, read by
+    deploy/policy_net.py:6-33): mean / std of the "state" normaliser, w{i} as [in, out] (Flax `kernel`), b{i}."""
+    import numpy as np
+    ns = ckpt["norm_state"]
+    cnt = float(ns["count"])
+    var = (ns["m2"].double() / max(cnt, 1.0)).clamp(min=1e-12)
+    std = torch.sqrt(var).clamp(min=1e-6) if cnt > 0 else torch.ones_like(var)
+    out = {"mean": ns["mean"].float().cpu().numpy(), "std": std.float().cpu().numpy()}
+    keys = sorted({int(k.split(".")[1]) for k in ckpt["model"] if k.startswith("policy.") and k.endswith(".weight")})
+    for i, li in enumerate(keys):
+        out[f"w{i}"] = ckpt["model"][f"policy.{li}.weight"].float().cpu().numpy().T.copy()
+        out[f"b{i}"] = ckpt["model"][f"policy.{li}.bias"].float().cpu().numpy()
+    np.savez_compressed(path, **out)

@@ -279,3 +279,38 @@ def test_configs3_wfc_dr_8192_full_size():
     assert bad == 0
     for e in (a, b, h0, h1):
         e.close()
+
+
+def test_rccl_metric_allreduce_single_rank():
+    """the one collective of the path through RCCL itself (backend "nccl" on ROCm): a one-rank process group on this box's GPU, the
+    fused 25-float all-reduce issued from the bench loop's MetricReducer after real env steps (the 8-GPU run is the driver's)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from phase_guided_terrain_traversal_amd import abi, configs
+from phase_guided_terrain_traversal_amd.distributed import MetricReducer, init_from_env
+from phase_guided_terrain_traversal_amd.env import Joystick
+rank, local, world = init_from_env("nccl", force=True)
+assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+torch.cuda.set_device(local)
+env = Joystick("flat_terrain", configs.training_config(), num_envs=256, device="cuda:0", autoreset=True)
+env.reset(seed=1)
+red = MetricReducer(torch.device("cuda", 0))
+tot = 0.0
+for k in range(20):
+    obs, reward, done, info = env.step(torch.zeros(256, 12, device="cuda"))
+    red.accumulate_block(env.step_block); tot += float(reward.sum())
+out = red.reduce()
+torch.cuda.synchronize()
+print(json.dumps({"env_steps": float(out["env_steps"]), "reward_mean": float(out["reward_mean"]), "expect": tot / (20 * 256)}))
+dist.destroy_process_group()
+""" % root
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    import json
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["env_steps"] == 20 * 256 and abs(d["reward_mean"] - d["expect"]) < 1e-5

@@ -20,6 +20,7 @@ from phase_guided_terrain_traversal_amd.env import Joystick
 from phase_guided_terrain_traversal_amd.randomize import domain_randomize
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+DEVICE = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))      # one process per GPU; this script trains on the GPU of its rank
 
 
 def load_terrain(spec):
@@ -38,14 +39,14 @@ def run_training(args):
     kw = {"params": torch.from_numpy(dr["params"])}
     if terrain is not None:
         kw.update(variant=torch.from_numpy(dr["variant"]), box_friction=torch.from_numpy(dr["box_friction"]))
-    env = Joystick(args.task_name, cfg, num_envs=args.num_envs, terrain=terrain, device="cuda:0", autoreset=True, **kw)
+    env = Joystick(args.task_name, cfg, num_envs=args.num_envs, terrain=terrain, device=DEVICE, autoreset=True, **kw)
     ckpt = os.path.join(ROOT, "checks_stairs", f"checkpoint_{args.index}")
     os.makedirs(ckpt, exist_ok=True)
     json.dump({k: v for k, v in cfg.items()}, open(os.path.join(ckpt, "config.json"), "w"), indent=4, default=str)
     restore = None
     if args.checkpoint_folder:
         steps = [int(f[:-3]) for f in os.listdir(args.checkpoint_folder) if f.endswith(".pt") and f[:-3].isdigit()]
-        restore = torch.load(os.path.join(args.checkpoint_folder, f"{max(steps)}.pt"), map_location="cuda:0")
+        restore = torch.load(os.path.join(args.checkpoint_folder, f"{max(steps)}.pt"), map_location=DEVICE)
         print("restoring", args.checkpoint_folder, max(steps))
     y, lin, ang, times = [], [], [], [time.time()]
 
@@ -64,10 +65,16 @@ def run_training(args):
                 return True
         return False
 
+    def save_params(num_steps, params):
+        """training/train.py:189-195: a checkpoint per evaluation (resume) plus a `policy{index}` file a deployment script can read
+        (here the npz layout of policy.PolicyMLP / tools/rollout_policy.py instead of a pickled Brax pytree)"""
+        torch.save(params, os.path.join(ckpt, f"{num_steps}.pt"))
+        ppo.export_policy_npz(params, os.path.join(ckpt, f"policy{args.index}.npz"))
+
     pcfg = ppo.PPOConfig(num_timesteps=args.num_timesteps, num_evals=args.num_evals, num_minibatches=args.num_minibatches,
                          batch_size=args.batch_size, discounting=args.discount, learning_rate=args.learning_rate, seed=args.index)
     model_, norms, hist = ppo.train(env, pcfg, progress_fn=progress,
-                                    policy_params_fn=lambda s, p: torch.save(p, os.path.join(ckpt, f"{s}.pt")), restore=restore)
+                                    policy_params_fn=save_params, restore=restore)
     print(f"time to train: {times[-1] - times[0]:.1f} s")
     os.makedirs(os.path.join(ROOT, "plots", args.method), exist_ok=True)
     np.save(os.path.join(ROOT, "plots", args.method, f"mean{args.index}"), np.array(y))
