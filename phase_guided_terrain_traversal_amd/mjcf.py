@@ -491,6 +491,17 @@ def model_from_json(text: str) -> Dict[str, Any]:
 _ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
 
 
+def with_bias_velocity(model: Dict[str, Any], kv: float) -> Dict[str, Any]:
+    """Copy of a compiled model with the actuators' velocity bias biasprm[:, 2] set to `kv`.  The shipped constants keep the
+    default class's -0.5 (go2_mjx_feetonly.xml:27); whether MuJoCo's <position> shortcut keeps or clears it is a parser detail
+    that cannot be checked here, so the value is a switch with a test on either side."""
+    out = dict(model)
+    b = np.array(model["act_bias"], dtype=np.float64, copy=True)
+    b[:, 2] = kv
+    out["act_bias"] = b
+    return out
+
+
 def load_model(task: str = "stairs") -> Dict[str, Any]:
     """Load the shipped, pre-compiled model constants (assets/go2_<task>.json).
 

@@ -57,3 +57,111 @@ def test_compiler_rejects_unsupported(tmp_path):
     p.write_text('<mujoco><compiler angle="degree"/><worldbody/></mujoco>')
     with pytest.raises(ValueError):
         mjcf.compile_mjcf(str(p))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Derived constants pinned WITHOUT mjcf.py and WITHOUT the oracle.  The numbers below are data of go2_mjx_feetonly.xml
+# (inertial elements :91-92,:104-105,:111-112,:118-119 and their mirrored copies :132-203; body offsets :89,:103,:110,:117;
+# joint axes :26-38; armature :26).  The method is independent of the compiler's: forward kinematics with rotation matrices
+# and velocity Jacobians by CENTRAL DIFFERENCES of the body poses (the compiler uses analytic Jacobians on quaternions).
+def _rot(axis, ang):
+    a = np.asarray(axis, float); a = a / np.linalg.norm(a)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+
+def _q2m(q):
+    w, x, y, z = np.asarray(q, float) / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+_BASE = dict(ipos=[0.021112, 0, -0.005366], iquat=[-0.000543471, 0.713435, -0.00173769, 0.700719], mass=6.921, I=[0.107027, 0.0980771, 0.0244531])
+# per leg (FL, FR, RL, RR): hip offset, then (inertial pos, inertial quat) of hip / thigh / calf
+_LEGS = [
+    dict(hip=[0.1934, 0.0465, 0], thigh=[0, 0.0955, 0], ih=([-0.0054, 0.00194, -0.000105], [0.497014, 0.499245, 0.505462, 0.498237]),
+         it=([-0.00374, -0.0223, -0.0327], [0.829533, 0.0847635, -0.0200632, 0.551623]), ic=([0.00629595, -0.000622121, -0.141417], [0.710672, 0.00154099, -0.00450087, 0.703508])),
+    dict(hip=[0.1934, -0.0465, 0], thigh=[0, -0.0955, 0], ih=([-0.0054, -0.00194, -0.000105], [0.498237, 0.505462, 0.499245, 0.497014]),
+         it=([-0.00374, 0.0223, -0.0327], [0.551623, -0.0200632, 0.0847635, 0.829533]), ic=([0.00629595, 0.000622121, -0.141417], [0.703508, -0.00450087, 0.00154099, 0.710672])),
+    dict(hip=[-0.1934, 0.0465, 0], thigh=[0, 0.0955, 0], ih=([0.0054, 0.00194, -0.000105], [0.505462, 0.498237, 0.497014, 0.499245]),
+         it=([-0.00374, -0.0223, -0.0327], [0.829533, 0.0847635, -0.0200632, 0.551623]), ic=([0.00629595, -0.000622121, -0.141417], [0.710672, 0.00154099, -0.00450087, 0.703508])),
+    dict(hip=[-0.1934, -0.0465, 0], thigh=[0, -0.0955, 0], ih=([0.0054, -0.00194, -0.000105], [0.499245, 0.497014, 0.498237, 0.505462]),
+         it=([-0.00374, 0.0223, -0.0327], [0.551623, -0.0200632, 0.0847635, 0.829533]), ic=([0.00629595, 0.000622121, -0.141417], [0.703508, -0.00450087, 0.00154099, 0.710672])),
+]
+_LINK = dict(mass=[0.678, 1.152, 0.241352], I=[[0.00088403, 0.000596003, 0.000479967], [0.00594973, 0.00584149, 0.000878787], [0.0014901, 0.00146356, 5.31397e-05]])
+_CALF = [0, 0, -0.213]
+_ARMATURE = 0.01
+
+
+def _poses(p0, R0, joints):
+    """COM position, inertial-frame rotation, mass, principal inertia of the 13 bodies"""
+    out = [(p0 + R0 @ np.array(_BASE["ipos"]), R0 @ _q2m(_BASE["iquat"]), _BASE["mass"], _BASE["I"])]
+    for l, leg in enumerate(_LEGS):
+        p, R = p0 + R0 @ np.array(leg["hip"]), R0 @ _rot([1, 0, 0], joints[3 * l])
+        out.append((p + R @ np.array(leg["ih"][0]), R @ _q2m(leg["ih"][1]), _LINK["mass"][0], _LINK["I"][0]))
+        p, R = p + R @ np.array(leg["thigh"]), R @ _rot([0, 1, 0], joints[3 * l + 1])
+        out.append((p + R @ np.array(leg["it"][0]), R @ _q2m(leg["it"][1]), _LINK["mass"][1], _LINK["I"][1]))
+        p, R = p + R @ np.array(_CALF), R @ _rot([0, 1, 0], joints[3 * l + 2])
+        out.append((p + R @ np.array(leg["ic"][0]), R @ _q2m(leg["ic"][1]), _LINK["mass"][2], _LINK["I"][2]))
+    return out
+
+
+def _independent_M0():
+    """M0 at qpos0 = (0, 0, 0.445, identity, joints 0) and the body Jacobians at the COMs, by central differences"""
+    eps = 1e-6
+    p0, R0, j0 = np.array([0, 0, 0.445]), np.eye(3), np.zeros(12)
+
+    def moved(i, s):        # dof i displaced by s: free joint = world-frame translation, BODY-frame rotation; then the hinges
+        if i < 3:
+            return p0 + s * np.eye(3)[i], R0, j0
+        if i < 6:
+            return p0, R0 @ _rot(np.eye(3)[i - 3], s), j0
+        j = j0.copy(); j[i - 6] += s
+        return p0, R0, j
+
+    ref = _poses(p0, R0, j0)
+    Jp = np.zeros((13, 3, 18)); Jr = np.zeros((13, 3, 18))
+    for i in range(18):
+        A, B = _poses(*moved(i, eps)), _poses(*moved(i, -eps))
+        for b in range(13):
+            Jp[b, :, i] = (A[b][0] - B[b][0]) / (2 * eps)
+            W = (A[b][1] - B[b][1]) / (2 * eps) @ ref[b][1].T           # dR/ds R^T = [omega]x
+            Jr[b, :, i] = [W[2, 1], W[0, 2], W[1, 0]]
+    M = np.zeros((18, 18))
+    for b in range(13):
+        Iw = ref[b][1] @ np.diag(ref[b][3]) @ ref[b][1].T
+        M += ref[b][2] * Jp[b].T @ Jp[b] + Jr[b].T @ Iw @ Jr[b]
+    M[6:, 6:] += _ARMATURE * np.eye(12)
+    return M, Jp, Jr
+
+
+def test_invweight0_and_meaninertia_pinned_independently():
+    """MuJoCo's compile-time set0: dof_invweight0 = diag(M0^-1) (free joint: mean over the 3 translational / rotational
+    dofs), body_invweight0 = (tr(Jp M0^-1 Jp^T) / 3, tr(Jr M0^-1 Jr^T) / 3) at the body COM, meaninertia = mean diag(M0).  These
+    feed every constraint row's regulariser R (go2_mjx_feetonly.xml contacts and limits) in BOTH the kernel and the oracle, so
+    they are checked here against a computation that shares no code with either."""
+    M, Jp, Jr = _independent_M0()
+    Minv = np.linalg.inv(M)
+    d = np.diag(Minv).copy(); d[0:3] = d[0:3].mean(); d[3:6] = d[3:6].mean()
+    biw = np.array([[np.trace(Jp[b] @ Minv @ Jp[b].T) / 3, np.trace(Jr[b] @ Minv @ Jr[b].T) / 3] for b in range(13)])
+    for task in ("flat_terrain", "stairs"):
+        m = mjcf.load_model(task)
+        assert abs(m["meaninertia"] - np.mean(np.diag(M))) < 1e-7 * m["meaninertia"]
+        assert np.allclose(m["dof_invweight0"], d, rtol=2e-6, atol=0)
+        assert np.allclose(m["body_invweight0"], biw, rtol=2e-6, atol=0)
+        assert abs(M[0, 0] - 15.206408) < 1e-6 and np.allclose(M[0:3, 0:3], 15.206408 * np.eye(3), atol=1e-6)      # total mass (SURVEY A2)
+    # the calf's translational invweight is what scales every foot-contact row
+    assert 0.05 < biw[3, 0] < 5.0 and np.allclose(biw[3], biw[6], rtol=1e-3)            # FL calf ~ FR calf (mirror images)
+
+
+def test_actuator_bias_velocity_gain_is_a_tested_switch():
+    """go2_mjx_feetonly.xml:27 sets biasprm="0 -50 -0.5" in the default class and declares the actuators with the <position>
+    shortcut, go2/base.py:57-61 then overwrites gainprm[:,0] = Kp and biasprm[:,1] = -Kp.  The shipped constants keep
+    biasprm[2] = -0.5 (actuator-level damping on top of the joint damping Kd); `compile_mjcf(..., keep_bias_velocity=False)` is
+    the other reading of the shortcut (kv absent -> 0).  tests/test_gpu_policy.py::test_bias_velocity_switch_against_policy_statistics
+    shows which one reproduces the statistics recorded in the reference's own trained policy."""
+    m = mjcf.load_model("stairs")
+    assert np.allclose(m["act_bias"][:, 2], -0.5) and np.allclose(m["act_bias"][:, 0], 0.0)
+    m0 = mjcf.with_bias_velocity(m, 0.0)
+    assert np.allclose(m0["act_bias"][:, 2], 0.0) and np.allclose(m0["act_bias"][:, 1], m["act_bias"][:, 1]) and m["act_bias"][0, 2] == -0.5

@@ -69,6 +69,14 @@ for name in NAMES:
     std = np.asarray(as_dict(nd["std"])["state"] if not isinstance(nd["std"], dict) else nd["std"]["state"], dtype=np.float32)
     pol = net["params"] if isinstance(net, dict) else as_dict(net)["policy"]["params"]
     out = {"mean": mean, "std": std}
+    # statistics of the privileged observation (215) as the training run saw them: distribution-level evidence about the
+    # reference's simulator (accelerometer, actuator forces, contact duty)
+    try:
+        pm = as_dict(nd["mean"]) if not isinstance(nd["mean"], dict) else nd["mean"]
+        ps = as_dict(nd["std"]) if not isinstance(nd["std"], dict) else nd["std"]
+        out["mean_priv"] = np.asarray(pm["privileged_state"], dtype=np.float32); out["std_priv"] = np.asarray(ps["privileged_state"], dtype=np.float32)
+    except Exception as ex:
+        print("  (no privileged statistics:", ex, ")")
     for i, layer in enumerate(pol):
         out[f"w{i}"] = np.asarray(pol[layer]["kernel"], dtype=np.float32)
         out[f"b{i}"] = np.asarray(pol[layer]["bias"], dtype=np.float32)
