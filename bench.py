@@ -13,9 +13,9 @@ Launch: under torchrun the ranks come from the environment; a bare `python bench
 N ranks itself (one process per GPU) and refuses when the node has fewer than N devices.
 
 Before the clock starts the whole timed loop body runs at least once per code path whatever --warmup says (one pass
-over the action pool with the kernel events recorded on every step, the per-step metric GEMV, two fused all-reduces):
+over the action pool with the kernel events recorded on every step, two interval reductions with their fused all-reduce):
 nothing in the timed window loads a code object or creates an event for the first time.  `wall_over_kernels` =
-ms_per_step / (physics + observe + metric GEMV kernel time); "cold": true (and exit code 3) when it exceeds 1.5.
+ms_per_step / (physics + observe + the interval reduction's share of a step); "cold": true (and exit code 3) when it exceeds 1.5.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (physics_kernel); `cpu_baseline` is the
 build's own CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded sample.
@@ -69,7 +69,7 @@ class StubEnv:
         from phase_guided_terrain_traversal_amd import abi
         self.num_envs = n
         self.step_block = torch.zeros((abi.NMETRIC + 2, n), dtype=torch.float32)
-        self.buffers = {"done": self.step_block[abi.NMETRIC + 1]}
+        self.buffers = {"done": self.step_block[abi.NMETRIC + 1], "interval_sums": torch.zeros((abi.NMETRIC + 2, n), dtype=torch.float32)}
         self._k, self._timed, self._rank = 0, 0, rank
 
     def reset(self, seed=0):
@@ -80,6 +80,7 @@ class StubEnv:
         self.step_block[:-2] = action.mean()
         self.step_block[-2] = 1.0 + self._rank      # "reward": rank-dependent so the all-reduce is checkable
         self.step_block[-1] = 0.0
+        self.buffers["interval_sums"] += self.step_block
         if self._timing:
             self._timed += 1
         return None, self.step_block[-2], self.step_block[-1], {}
@@ -158,12 +159,16 @@ def worker(args):
     reducer = MetricReducer(dev)
     env_steps_seen = torch.zeros((), dtype=torch.float64, device=dev)     # sum of the all-reduced env-step counts
 
+    sums = env.buffers["interval_sums"]          # [22 metrics; reward; done][N] running sums kept by the step kernels
+
+    def flush(nsteps):
+        env_steps_seen.add_(reducer.reduce_block(sums, float(nsteps) * n)["env_steps"])
+
     def run(k0, k1):
         for k in range(k0, k1):
             env.step(pool[k % len(pool)])
-            reducer.accumulate_block(env.step_block)
             if (k + 1) % REDUCE_EVERY == 0:
-                env_steps_seen.add_(reducer.reduce()["env_steps"])
+                flush(REDUCE_EVERY)
 
     # ---- prime: every code path of the timed loop, whatever --warmup is (the driver runs --steps 20 --warmup 5)
     env.enable_timing(1)                                   # events recorded around the kernels of EVERY step
@@ -171,20 +176,19 @@ def worker(args):
     sync()
     env.kernel_ms_mean()                                   # the read-back path of the event ring
     gemv_ms = 0.0
-    if not stub:                                           # duration of the per-step metric GEMV (torch launch on the same stream)
+    if not stub:                                           # duration of one interval reduction (GEMV + clear + all-reduce), spread over its steps
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(16):
-            reducer.accumulate_block(env.step_block)
+        for _ in range(8):
+            reducer.reduce_block(sums, 0.0)
         e1.record(); sync()
-        gemv_ms = e0.elapsed_time(e1) / 16
-    reducer.reduce(); env_steps_seen.zero_()               # counters back to zero
+        gemv_ms = e0.elapsed_time(e1) / 8 / REDUCE_EVERY
+    sums.zero_(); reducer.reduce(); env_steps_seen.zero_()               # counters back to zero
     # ---- the W untimed warm-up steps of the contract
     env.enable_timing(8)          # every 8th step: an event record costs a few us of GPU idle
     run(0, args.warmup)
     sync()
-    if args.warmup % REDUCE_EVERY:
-        reducer.reduce()
+    sums.zero_(); reducer.reduce()
     env_steps_seen.zero_()
     env.enable_timing(8)                                   # timing counters back to zero: means are over the timed steps only
     if world > 1:
@@ -199,7 +203,7 @@ def worker(args):
     dt = time.perf_counter() - t0
     ranks = 1
     if args.steps % REDUCE_EVERY:
-        env_steps_seen.add_(reducer.reduce()["env_steps"])  # the tail of the last interval (outside the clock)
+        flush(args.steps % REDUCE_EVERY)                    # the tail of the last interval (outside the clock)
     if world > 1:
         t = torch.tensor([dt, 1.0], device=dev, dtype=torch.float64)
         tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -237,7 +241,7 @@ def worker(args):
                        "envs_per_gpu": n, "substeps": 4, "autoreset": True, "actions": "tanh(N(0,0.6)) iid", "parallelism": f"env-shard x{world}",
                        "collective": f"fused {MetricReducer.SIZE}-float all-reduce every {REDUCE_EVERY} steps ({args.backend})"},
             "env_steps_allreduced": env_steps, "env_steps_expected": float(n) * world * args.steps,
-            "kernels_ms": {"physics_kernel": phys_ms, "observe_kernel": obs_ms, "metric_gemv": gemv_ms, "launches": ntimed},
+            "kernels_ms": {"physics_kernel": phys_ms, "observe_kernel": obs_ms, "interval_reduce_per_step": gemv_ms, "launches": ntimed},
             "wall_over_kernels": ratio, "cold": bool(ratio > COLD_RATIO),
             "done_fraction_last_step": done_frac,
             "roofline": {"bound": "valu_fp32", "achieved": algo_flop / (phys_ms * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",

@@ -138,7 +138,7 @@ class HostBuffers:
         for spec in abi.BUFFER_SPECS:
             self.arrays[spec[0]] = np.zeros(abi.buffer_shape(spec, n, method), dtype=spec[2])
         opt = dict(params=with_params, variant=with_variant, box_friction=with_box_friction, dbg_contact=debug,
-                   dbg_dist=debug, dbg_niter=debug)
+                   dbg_dist=debug, dbg_niter=debug, interval_sums=True)
         for spec in abi.OPTIONAL_SPECS:
             if opt[spec[0]]:
                 self.arrays[spec[0]] = np.zeros(abi.buffer_shape(spec, n), dtype=spec[2])

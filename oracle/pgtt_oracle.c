@@ -359,6 +359,11 @@ void pgtt_oracle_set_diag(double* resid_N_or_null) { g_diag_resid = resid_N_or_n
       }                                                                                                                  \
       B->reward[e] = (float)reward; B->done[e] = (float)idone;                                                           \
       for (int k = 0; k < PGTT_NMETRIC; k++) B->metrics[(long)k*N + e] = (float)metrics[k];                              \
+      if (B->interval_sums) {                                                                                            \
+        for (int k = 0; k < PGTT_NMETRIC; k++) B->interval_sums[(long)k*N + e] += (float)metrics[k];                     \
+        B->interval_sums[(long)PGTT_NMETRIC*N + e] += (float)reward;                                                     \
+        B->interval_sums[(long)(PGTT_NMETRIC + 1)*N + e] += (float)idone;                                                \
+      }                                                                                                                  \
       free(d);                                                                                                           \
     }                                                                                                                    \
   }

@@ -81,7 +81,7 @@ class PgttBuffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "state", "istate", "frame", "scan_z", "obs_state", "obs_priv", "reward", "done", "metrics",
         "first_state", "first_obs", "ep_metrics", "params", "variant", "box_friction", "dbg_contact",
-        "dbg_dist", "dbg_niter")]
+        "dbg_dist", "dbg_niter", "interval_sums")]
 
 
 # (name, rows-or-cols, dtype, layout) ; layout "soa" => [rows][N], "aos" => [N][cols]
@@ -97,6 +97,7 @@ OPTIONAL_SPECS = [
     ("params", NPARAM, np.float32, "soa"), ("variant", 1, np.int32, "vec"),
     ("box_friction", MAX_BOX, np.float32, "soa"), ("dbg_contact", NCON * 2, np.int32, "aos"),
     ("dbg_dist", NCON, np.float32, "aos"), ("dbg_niter", 1, np.int32, "vec"),
+    ("interval_sums", NMETRIC + 2, np.float32, "soa"),
 ]
 
 

@@ -867,7 +867,10 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
 #pragma unroll
     for (int j = 0; j < PGTT_NMETRIC; j++) if (j == k) v = metrics[j];
     a.buf.metrics[k * (long)N + e] = v;
+    if (OMODE == OBS_STEP && a.buf.interval_sums) a.buf.interval_sums[k * (long)N + e] += v;
   }
+  if (OMODE == OBS_STEP && a.buf.interval_sums && lane < 2)
+    a.buf.interval_sums[(PGTT_NMETRIC + lane) * (long)N + e] += lane == 0 ? reward : (wdone ? 1.f : 0.f);
   const bool restore = OMODE == OBS_STEP && cfg->autoreset && wdone && a.buf.first_state && a.buf.first_obs;
   if (restore) {
     for (int r = lane; r < PGTT_S_CMD; r += 64) S[r * (long)N + e] = a.buf.first_state[r * (long)N + e];
@@ -987,6 +990,12 @@ __global__ __launch_bounds__(64) void task_kernel(KArgs a, const float* __restri
   a.buf.reward[e] = t.reward; a.buf.done[e] = wdone ? 1.f : 0.f;
 #pragma unroll
   for (int k = 0; k < PGTT_NMETRIC; k++) a.buf.metrics[k * (long)N + e] = t.metrics[k];
+  if (a.buf.interval_sums) {
+#pragma unroll
+    for (int k = 0; k < PGTT_NMETRIC; k++) a.buf.interval_sums[k * (long)N + e] += t.metrics[k];
+    a.buf.interval_sums[PGTT_NMETRIC * (long)N + e] += t.reward;
+    a.buf.interval_sums[(PGTT_NMETRIC + 1) * (long)N + e] += wdone ? 1.f : 0.f;
+  }
   // AutoReset: a finished episode continues from the env's first state and first observation
   if (cfg->autoreset && wdone && a.buf.first_state && a.buf.first_obs) {
     for (int r = 0; r < PGTT_S_CMD; r++) S[r * (long)N + e] = a.buf.first_state[r * (long)N + e];

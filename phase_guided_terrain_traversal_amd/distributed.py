@@ -65,6 +65,17 @@ class MetricReducer:
         self.acc[:abi.NMETRIC + 2].addmv_(block, self._ones)
         self.count += float(n)
 
+    def reduce_block(self, sums: torch.Tensor, env_steps: float) -> Dict[str, torch.Tensor]:
+        """`Joystick.buffers["interval_sums"]` ([22 metrics; reward; done][N], kept by the step kernels) over `env_steps` env-steps
+        of this rank: ONE GEMV over the envs for the whole interval, the block cleared for the next one, then the fused all-reduce."""
+        n = sums.shape[1]
+        if self._ones is None or self._ones.shape[0] != n:
+            self._ones = torch.ones(n, dtype=torch.float32, device=sums.device)
+        self.acc[:abi.NMETRIC + 2].addmv_(sums, self._ones)
+        sums.zero_()
+        self.count += float(env_steps)
+        return self.reduce()
+
     def reduce(self) -> Dict[str, torch.Tensor]:
         """Sum over ranks (one RCCL all-reduce), reset the local accumulator, return global means."""
         buf = self.acc.clone()

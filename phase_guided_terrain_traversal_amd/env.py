@@ -59,6 +59,9 @@ class Joystick:
         self.buffers["metrics"] = self.step_block[:abi.NMETRIC]
         self.buffers["reward"] = self.step_block[abi.NMETRIC]
         self.buffers["done"] = self.step_block[abi.NMETRIC + 1]
+        # per-env running sums of [22 metrics; reward; done] since the trainer last cleared them: a log interval then costs one
+        # reduction over the envs (distributed.MetricReducer.reduce_block), not one per step
+        self.buffers["interval_sums"] = torch.zeros((abi.NMETRIC + 2, n), dtype=torch.float32, device=self.device)
         if params is not None:
             self.buffers["params"] = params.to(self.device, torch.float32).contiguous()
             assert self.buffers["params"].shape == (abi.NPARAM, n)

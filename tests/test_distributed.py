@@ -33,6 +33,13 @@ out = red.reduce()
 exp_m = full_m.sum(0).sum(1) / 3000.0
 ok = torch.allclose(out["metrics_mean"], exp_m, atol=1e-5) and abs(float(out["reward_mean"]) - float(full_r.mean())) < 1e-5 \
      and float(out["done_count"]) == float(full_d.sum()) and float(out["env_steps"]) == 3000.0 and float(red.acc.abs().sum()) == 0.0
+# the interval form bench.py uses: per-env running sums kept by the step kernels, ONE GEMV + the fused all-reduce per interval
+sums = torch.zeros(abi.NMETRIC + 2, n)
+for k in range(3):
+    sums += torch.cat([full_m[k][:, lo:hi], full_r[k][None, lo:hi], full_d[k][None, lo:hi]], 0)
+out2 = red.reduce_block(sums, 3.0 * n)
+ok = ok and torch.allclose(out2["metrics_mean"], exp_m, atol=1e-5) and float(out2["env_steps"]) == 3000.0 and float(sums.abs().sum()) == 0.0 \
+     and float(out2["done_count"]) == float(full_d.sum())
 print(json.dumps({"rank": rank, "ok": bool(ok), "lo": lo, "hi": hi}))
 dist.destroy_process_group()
 '''

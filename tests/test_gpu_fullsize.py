@@ -314,3 +314,23 @@ dist.destroy_process_group()
     import json
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert d["env_steps"] == 20 * 256 and abs(d["reward_mean"] - d["expect"]) < 1e-5
+
+
+@pytest.mark.parametrize("observe", ["fused", "split"])
+def test_interval_sums_equal_the_per_step_sums(observe, monkeypatch):
+    """buffers["interval_sums"]: the running per-env sums of [22 metrics; reward; done] kept by the step kernels are the sums of
+    the per-step outputs (same additions in the same order: bitwise), AutoReset on, until the caller clears the block"""
+    monkeypatch.setenv("PGTT_OBSERVE", observe)
+    env, _, _ = make(n=1024, level="level13")
+    env.reset(seed=2)
+    ref = torch.zeros_like(env.buffers["interval_sums"])
+    for k in range(25):
+        env.step(actions(k, 1024))
+        ref[:abi.NMETRIC] += env.buffers["metrics"]; ref[abi.NMETRIC] += env.buffers["reward"]; ref[abi.NMETRIC + 1] += env.buffers["done"]
+    torch.cuda.synchronize()
+    assert torch.equal(env.buffers["interval_sums"], ref) and float(ref[abi.NMETRIC + 1].sum()) > 0
+    from phase_guided_terrain_traversal_amd.distributed import MetricReducer
+    out = MetricReducer(torch.device("cuda", 0)).reduce_block(env.buffers["interval_sums"], 25.0 * 1024)
+    assert float(env.buffers["interval_sums"].abs().sum()) == 0.0 and float(out["env_steps"]) == 25 * 1024
+    assert abs(float(out["reward_mean"]) - float(ref[abi.NMETRIC].sum()) / (25 * 1024)) < 1e-6
+    env.close()
