@@ -1273,21 +1273,23 @@ struct QSolver {
   // Two constraint rows at NA trial steps, in packed fp32 (v_pk_*: two rows per instruction).  The quadratic pieces
   // h = D * (ja^2/2, jv ja, jv^2/2) are formed once and added where the row is active (ja + alpha jv < 0); m * h with
   // m in {0, 1} is exact, so the sums are those of an un-fused evaluation (even and odd rows in separate chains).
-  template <int NA>
+  template <int NA, bool COST = true>
   PG_INL static void ls_row2(f2 ja, f2 jv, float D, const float* al, f2 (*q)[3]) {
     const f2 h0 = D * (0.5f * ja * ja), h1 = D * (jv * ja), h2 = D * (0.5f * jv * jv);
 #pragma unroll
     for (int a = 0; a < NA; a++) {
       const f2 x = ja + al[a] * jv;
       f2 mk; mk.x = x.x < 0.f ? 1.0f : 0.f; mk.y = x.y < 0.f ? 1.0f : 0.f;
-      q[a][0] = __builtin_elementwise_fma(mk, h0, q[a][0]);
+      if (COST) q[a][0] = __builtin_elementwise_fma(mk, h0, q[a][0]);
       q[a][1] = __builtin_elementwise_fma(mk, h1, q[a][1]);
       q[a][2] = __builtin_elementwise_fma(mk, h2, q[a][2]);
     }
   }
 
   // cost and derivatives along the search direction at NA steps; the rows are read ONCE for all NA steps
-  template <int NA>
+  // COST = false: the derivatives alone (the bracketing rounds only look at d0 / d1; the costs of the two points the search
+  // ends with are evaluated once, afterwards - same function of alpha, same bits)
+  template <int NA, bool COST = true>
   PG_INL void ls_points(const float* al, const float* jv_lim, const float* jv0, float qg0, float qg1, float qg2, LSPoint* out) const {
     f2 q[NA][3];
 #pragma unroll
@@ -1297,46 +1299,50 @@ struct QSolver {
         // the three limit rows have their own D each: pairs (row0, row1) and (row2, empty)
         const f2 ja01{jar_lim[0], jar_lim[1]}, jv01{jv_lim[0], jv_lim[1]}, D01{s.lim_D[0], s.lim_D[1]};
         const f2 ja2{jar_lim[2], 0.f}, jv2{jv_lim[2], 0.f}, D2{s.lim_D[2], 0.f};
-        ls_row2d<NA>(ja01, jv01, D01, al, q);
-        ls_row2d<NA>(ja2, jv2, D2, al, q);
+        ls_row2d<NA, COST>(ja01, jv01, D01, al, q);
+        ls_row2d<NA, COST>(ja2, jv2, D2, al, q);
       }
       if (any_con0) {
-        ls_row2<NA>(f2{jar0[0], jar0[1]}, f2{jv0[0], jv0[1]}, s.con0.D, al, q);
-        ls_row2<NA>(f2{jar0[2], jar0[3]}, f2{jv0[2], jv0[3]}, s.con0.D, al, q);
+        ls_row2<NA, COST>(f2{jar0[0], jar0[1]}, f2{jv0[0], jv0[1]}, s.con0.D, al, q);
+        ls_row2<NA, COST>(f2{jar0[2], jar0[3]}, f2{jv0[2], jv0[3]}, s.con0.D, al, q);
       }
       for (int k = 0; k < nslots; k++) {
         const float Dk = slots.at(k, 2);
-        ls_row2<NA>(f2{slots.jar(k, 0), slots.jar(k, 1)}, f2{slots.jv(k, 0), slots.jv(k, 1)}, Dk, al, q);
-        ls_row2<NA>(f2{slots.jar(k, 2), slots.jar(k, 3)}, f2{slots.jv(k, 2), slots.jv(k, 3)}, Dk, al, q);
+        ls_row2<NA, COST>(f2{slots.jar(k, 0), slots.jar(k, 1)}, f2{slots.jv(k, 0), slots.jv(k, 1)}, Dk, al, q);
+        ls_row2<NA, COST>(f2{slots.jar(k, 2), slots.jar(k, 3)}, f2{slots.jv(k, 2), slots.jv(k, 3)}, Dk, al, q);
       }
     } else {
       // hex layout: sub-lane r evaluates row r of every constraint of its leg (limit row r < 3, pyramid row r of the
       // plane contact and of each box slot); the sums below run over all 16 lanes of the env
       const int r = threadIdx.x & 3;
-      if (any_lim || any_con0) ls_row2d<NA>(hx_ja, hx_jv, hx_D, al, q);       // own (limit row, plane row), picked once per search
-      if (nslots > 0) ls_row2d<NA>(ls_ja[0], ls_jv[0], ls_D[0], al, q);
-      if (nslots > 2) ls_row2d<NA>(ls_ja[1], ls_jv[1], ls_D[1], al, q);
+      if (any_lim || any_con0) ls_row2d<NA, COST>(hx_ja, hx_jv, hx_D, al, q);       // own (limit row, plane row), picked once per search
+      if (nslots > 0) ls_row2d<NA, COST>(ls_ja[0], ls_jv[0], ls_D[0], al, q);
+      if (nslots > 2) ls_row2d<NA, COST>(ls_ja[1], ls_jv[1], ls_D[1], al, q);
     }
 #pragma unroll
     for (int a = 0; a < NA; a++) {
-      const float q0 = quad_sum(sub_sum(q[a][0].x + q[a][0].y)) + qg0, q1 = quad_sum(sub_sum(q[a][1].x + q[a][1].y)) + qg1,
-                  q2 = quad_sum(sub_sum(q[a][2].x + q[a][2].y)) + qg2;
+      const float q1 = quad_sum(sub_sum(q[a][1].x + q[a][1].y)) + qg1, q2 = quad_sum(sub_sum(q[a][2].x + q[a][2].y)) + qg2;
       const float alpha = al[a];
       out[a].alpha = alpha;
-      out[a].cost = alpha * alpha * q2 + alpha * q1 + q0;
+      if (COST) {
+        const float q0 = quad_sum(sub_sum(q[a][0].x + q[a][0].y)) + qg0;
+        out[a].cost = alpha * alpha * q2 + alpha * q1 + q0;
+      } else {
+        out[a].cost = 0.f;
+      }
       out[a].d0 = 2.0f * alpha * q2 + q1;
       out[a].d1 = 2.0f * q2 + (q2 == 0.f ? kMinVal : 0.f);
     }
   }
   // same with one D per row
-  template <int NA>
+  template <int NA, bool COST = true>
   PG_INL static void ls_row2d(f2 ja, f2 jv, f2 D, const float* al, f2 (*q)[3]) {
     const f2 h0 = D * (0.5f * ja * ja), h1 = D * (jv * ja), h2 = D * (0.5f * jv * jv);
 #pragma unroll
     for (int a = 0; a < NA; a++) {
       const f2 x = ja + al[a] * jv;
       f2 mk; mk.x = x.x < 0.f ? 1.0f : 0.f; mk.y = x.y < 0.f ? 1.0f : 0.f;
-      q[a][0] = __builtin_elementwise_fma(mk, h0, q[a][0]);
+      if (COST) q[a][0] = __builtin_elementwise_fma(mk, h0, q[a][0]);
       q[a][1] = __builtin_elementwise_fma(mk, h1, q[a][1]);
       q[a][2] = __builtin_elementwise_fma(mk, h2, q[a][2]);
     }
@@ -1416,7 +1422,7 @@ struct QSolver {
       moved = k1 | k2 | k3;
       LSPoint r;
       r.alpha = k3 ? c3.alpha : (k2 ? c2.alpha : (k1 ? c1.alpha : x.alpha));
-      r.cost = k3 ? c3.cost : (k2 ? c2.cost : (k1 ? c1.cost : x.cost));
+      r.cost = 0.f;
       r.d0 = k3 ? c3.d0 : (k2 ? c2.d0 : (k1 ? c1.d0 : x.d0));
       r.d1 = k3 ? c3.d1 : (k2 ? c2.d1 : (k1 ? c1.d1 : x.d1));
       return r;
@@ -1436,11 +1442,17 @@ struct QSolver {
 #endif
       const float al3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha)};
       LSPoint pt[3];
-      ls_points<3>(al3, jv_lim, jv0, qg0, qg1, qg2, pt);
+      ls_points<3, false>(al3, jv_lim, jv0, qg0, qg1, qg2, pt);
       bool ml, mh;
       const LSPoint nlo = tighten(lo, pt[0], pt[2], pt[1], ml);
       const LSPoint nhi = tighten(hi, pt[1], pt[2], pt[0], mh);
       if (!done) { lo = nlo; hi = nhi; swap = ml | mh; it++; }
+    }
+    {   // costs of the two points the bracket ended with
+      const float al2[2] = {lo.alpha, hi.alpha};
+      LSPoint fin[2];
+      ls_points<2, true>(al2, jv_lim, jv0, qg0, qg1, qg2, fin);
+      lo.cost = fin[0].cost; hi.cost = fin[1].cost;
     }
     bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
     float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
