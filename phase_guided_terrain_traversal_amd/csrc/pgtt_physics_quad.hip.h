@@ -1222,6 +1222,41 @@ struct QSolver {
         for (int j = 0; j <= i; j++) llt[tri(i, j)] += dot(col[6 + i], y[6 + j]);
       }
     };
+    auto add_hessian_set = [&](const QContact& cn, const float* ja4, float* Gt, float* lbt, float* llt) {
+      float w[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) w[r] = ja4[r] < 0.f ? cn.D : 0.f;
+      float mu = cn.mu;
+      float W00 = w[0] + w[1] + w[2] + w[3], W01 = mu * (w[0] - w[1]), W02 = mu * (w[2] - w[3]);
+      float W11 = mu * mu * (w[0] + w[1]), W22 = mu * mu * (w[2] + w[3]);
+      // world-frame weight A = F^T Wc F (symmetric 3x3), then G = col^T A col over the 9 Jacobian columns
+      V3 r0 = cn.fr[0] * W00 + cn.fr[1] * W01 + cn.fr[2] * W02, r1 = cn.fr[0] * W01 + cn.fr[1] * W11, r2 = cn.fr[0] * W02 + cn.fr[2] * W22;
+      V3 Ax = v3(cn.fr[0].x * r0.x + cn.fr[1].x * r1.x + cn.fr[2].x * r2.x, cn.fr[0].x * r0.y + cn.fr[1].x * r1.y + cn.fr[2].x * r2.y, cn.fr[0].x * r0.z + cn.fr[1].x * r1.z + cn.fr[2].x * r2.z);
+      V3 Ay = v3(Ax.y, cn.fr[0].y * r0.y + cn.fr[1].y * r1.y + cn.fr[2].y * r2.y, cn.fr[0].y * r0.z + cn.fr[1].y * r1.z + cn.fr[2].y * r2.z);
+      V3 Az = v3(Ax.z, Ay.z, cn.fr[0].z * r0.z + cn.fr[1].z * r1.z + cn.fr[2].z * r2.z);
+      V3 col[9], y[9];
+      col[0] = v3(1, 0, 0); col[1] = v3(0, 1, 0); col[2] = v3(0, 0, 1);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { col[3 + k] = s.cdr[k].l + cross(s.cdr[k].a, cn.off); col[6 + k] = s.cdl[k].l + cross(s.cdl[k].a, cn.off); }
+      // The first three columns are the identity: y[0..2] are the columns of A, an entry G[i][j] with j < 3 is component
+      // j of y[i] (A is symmetric; same products in the same order as dot(col[i], y[j])) - 24 of the 45 entries cost no
+      // arithmetic (the compiler may not drop the 0 * x terms of the generic dot products by itself)
+      y[0] = Ax; y[1] = Ay; y[2] = Az;
+#pragma unroll
+      for (int k = 3; k < 9; k++) y[k] = v3(dot(Ax, col[k]), dot(Ay, col[k]), dot(Az, col[k]));
+      auto comp = [](V3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); };
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) Gt[tri(i, j)] = j < 3 ? comp(y[i], j) : dot(col[i], y[j]);
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) lbt[i * 6 + k] = k < 3 ? comp(y[6 + i], k) : dot(col[6 + i], y[k]);
+#pragma unroll
+        for (int j = 0; j <= i; j++) llt[tri(i, j)] = dot(col[6 + i], y[6 + j]);
+      }
+    };
     if (any_con0 && !plane_sub) add_hessian(s.con0, jar0, Gbb, H.lb, H.ll);
     if (kSubs == 1) {
       for (int k = 0; k < nslots; k++) {
@@ -1232,16 +1267,12 @@ struct QSolver {
     } else if (own_any()) {
       // hex layout: the owner of a slot forms its 45 Hessian entries; the sub-lane sums give every lane the leg's total
       float Gd[21], lbd[18], lld[6];
-#pragma unroll
-      for (int i = 0; i < 21; i++) Gd[i] = 0.f;
-#pragma unroll
-      for (int i = 0; i < 18; i++) lbd[i] = 0.f;
-#pragma unroll
-      for (int i = 0; i < 6; i++) lld[i] = 0.f;
-      for (int k0 = 0; k0 < 1; k0++) {
-        const int k = (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
-        if (!own_on(k)) continue;
-        add_hessian(mine, mjar, Gd, lbd, lld);
+      {
+        // a sub-lane whose slot is not in use contributes exact zeros: its weight is forced to 0 (every field of a slot record
+        // is finite, BoxSlots::clear_all) instead of branching round the products and pre-clearing 45 accumulators
+        QContact cn = mine;
+        cn.D = own_on((int)(threadIdx.x & 3)) ? cn.D : 0.f;
+        add_hessian_set(cn, mjar, Gd, lbd, lld);
       }
 #pragma unroll
       for (int i = 0; i < 21; i++) Gbb[i] += sub_sum(Gd[i]);
