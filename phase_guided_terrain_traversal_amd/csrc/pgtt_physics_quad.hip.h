@@ -1304,20 +1304,14 @@ struct QSolver {
   // Two constraint rows at NA trial steps, in packed fp32 (v_pk_*: two rows per instruction).  The quadratic pieces
   // h = D * (ja^2/2, jv ja, jv^2/2) are formed once and added where the row is active (ja + alpha jv < 0); m * h with
   // m in {0, 1} is exact, so the sums are those of an un-fused evaluation (even and odd rows in separate chains).
+  // mk = (ja + alpha jv < 0) ? 1 : 0 for two rows WITHOUT compares and selects: t = fma(alpha, -2^64 jv, -2^64 ja) is exactly
+  // -2^64 (ja + alpha jv) (binary scaling commutes with the rounding of the fma), and the saturating packed multiply
+  // clamp(t * 2^100) maps every t > 0 - down to the smallest scaled denormal - to 1 and t <= 0 / NaN to 0
+  // (tools/probes/satmul_probe.hip: checked against `x < 0` on 2^20 bit patterns incl. denormals, +-0, NaN, +-inf).
+  // Two packed instructions per row pair and trial step instead of a packed fma, two compares and two selects.
+  PG_INL static f2 sat_mul(f2 a, f2 b) { f2 r; asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
   template <int NA, bool COST = true>
-  PG_INL static void ls_row2(f2 ja, f2 jv, float D, const float* al, f2 (*q)[3]) {
-    const f2 h0 = D * (0.5f * ja * ja), h1 = D * (jv * ja), h2 = D * (0.5f * jv * jv);
-#pragma unroll
-    for (int a = 0; a < NA; a++) {
-      const f2 x = ja + al[a] * jv;
-      f2 mk; mk.x = x.x < 0.f ? 1.0f : 0.f; mk.y = x.y < 0.f ? 1.0f : 0.f;
-      if (COST) q[a][0] = __builtin_elementwise_fma(mk, h0, q[a][0]);
-      q[a][1] = __builtin_elementwise_fma(mk, h1, q[a][1]);
-      q[a][2] = __builtin_elementwise_fma(mk, h2, q[a][2]);
-    }
-  }
-
-  // cost and derivatives along the search direction at NA steps; the rows are read ONCE for all NA steps
+  PG_INL static void ls_row2(f2 ja, f2 jv, float D, const float* al, f2 (*q)[3]) { ls_row2d<NA, COST>(ja, jv, f2{D, D}, al, q); }
   // COST = false: the derivatives alone (the bracketing rounds only look at d0 / d1; the costs of the two points the search
   // ends with are evaluated once, afterwards - same function of alpha, same bits)
   template <int NA, bool COST = true>
@@ -1369,10 +1363,11 @@ struct QSolver {
   template <int NA, bool COST = true>
   PG_INL static void ls_row2d(f2 ja, f2 jv, f2 D, const float* al, f2 (*q)[3]) {
     const f2 h0 = D * (0.5f * ja * ja), h1 = D * (jv * ja), h2 = D * (0.5f * jv * jv);
+    const f2 jaK = ja * -0x1p64f, jvK = jv * -0x1p64f;
 #pragma unroll
     for (int a = 0; a < NA; a++) {
-      const f2 x = ja + al[a] * jv;
-      f2 mk; mk.x = x.x < 0.f ? 1.0f : 0.f; mk.y = x.y < 0.f ? 1.0f : 0.f;
+      const f2 t = __builtin_elementwise_fma(f2{al[a], al[a]}, jvK, jaK);
+      const f2 mk = sat_mul(t, f2{0x1p100f, 0x1p100f});
       if (COST) q[a][0] = __builtin_elementwise_fma(mk, h0, q[a][0]);
       q[a][1] = __builtin_elementwise_fma(mk, h1, q[a][1]);
       q[a][2] = __builtin_elementwise_fma(mk, h2, q[a][2]);
