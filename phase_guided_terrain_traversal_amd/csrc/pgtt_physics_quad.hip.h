@@ -1374,6 +1374,14 @@ struct QSolver {
     }
   }
 
+  // a / b for a denominator in the normal range (the curvature of the line-search quadratic): reciprocal and multiply, the
+  // same mantissa arithmetic as the 1-ulp division of this build without its frexp / ldexp range scaling; the product is
+  // kept out of fp contraction so that `alpha - a / b` rounds the quotient first, like the division did
+  PG_INL static float div_normal(float a, float b) {
+#pragma clang fp contract(off)
+    return a * __builtin_amdgcn_rcpf(b);
+  }
+
   PG_INL void linesearch(bool frozen) {
     float snb = 0.f, snl = 0.f;
 #pragma unroll
@@ -1455,7 +1463,7 @@ struct QSolver {
     };
     LSPoint p0, lo0;
     { const float a0 = 0.f; ls_points<1>(&a0, jv_lim, jv0, qg0, qg1, qg2, &p0); }
-    { const float a1 = p0.alpha - p0.d0 / p0.d1; ls_points<1>(&a1, jv_lim, jv0, qg0, qg1, qg2, &lo0); }
+    { const float a1 = p0.alpha - div_normal(p0.d0, p0.d1); ls_points<1>(&a1, jv_lim, jv0, qg0, qg1, qg2, &lo0); }
     bool lesser = lo0.d0 < p0.d0;
     LSPoint hi = lesser ? p0 : lo0, lo = lesser ? lo0 : p0;
     bool swap = true; int it = 0;
@@ -1466,7 +1474,7 @@ struct QSolver {
       s.cyc[18] += 1.f;           // line-search rounds executed by this wave
       s.cyc[19] += done ? 0.f : 1.f;   // ... of which this env needed
 #endif
-      const float al3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha)};
+      const float al3[3] = {lo.alpha - div_normal(lo.d0, lo.d1), hi.alpha - div_normal(hi.d0, hi.d1), 0.5f * (lo.alpha + hi.alpha)};
       LSPoint pt[3];
       ls_points<3, false>(al3, jv_lim, jv0, qg0, qg1, qg2, pt);
       bool ml, mh;
