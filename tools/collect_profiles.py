@@ -1,10 +1,10 @@
 """Copy the summaries of one tools/profile_round.sh run from gpurun_out/<tag>/ into profiles/ (tracked) and refresh
-   profiles/hbm_traffic.json (read by bench.py for roofline.traffic).   usage: python tools/collect_profiles.py r01g "note" """
+   profiles/hbm_traffic.json (read by bench.py for roofline.traffic).   usage: python tools/collect_profiles.py r02b "note" """
 import json, os, re, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, note = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
-for a, b in (("bench_level4.json", "level4_bench.json"), ("bench_flat.json", "flat_bench.json"), ("bench_wfc_dr_8192.json", "wfc_dr_8192_bench.json"),
+for a, b in (("driver_cmd_bench.json", "driver_cmd_bench.json"), ("bench_level4.json", "level4_bench.json"), ("bench_flat.json", "flat_bench.json"), ("bench_wfc_dr_8192.json", "wfc_dr_8192_bench.json"),
              ("bench_level4_quad.json", "level4_quad_layout_bench.json"), ("kernel_stats.csv", "level4_kernel_stats.csv")):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, f"{tag}_{b}"))
