@@ -21,8 +21,16 @@ for ln in body.splitlines():
         val[m.group(1)] = float(m.group(2)) * 1024
 tp = os.path.join(dst, "hbm_traffic.json")
 t = json.load(open(tp))
-t["level4_4096"] = {"physics_bytes_per_launch": val["FETCH_SIZE"] + val["WRITE_SIZE"], "fetch_bytes": val["FETCH_SIZE"], "write_bytes": val["WRITE_SIZE"],
-                    "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KB*1024 (profiles/{tag}_level4_pmc_summary.txt). Below the algorithmic 14.2 MB: "
-                            "the 4096-env working set (~2.8 MB state + frame) stays resident in L2 / Infinity Cache between the two kernels of a step"}
+# gfx950 correction (MI355X_MICROARCH.md "HBM"; calibrated on this library's own access pattern with tools/probes/traffic_calib.hip -
+# 4-byte-per-lane coalesced SoA rows, 256 MiB read and written: FETCH_SIZE reports exactly 1/2 of the bytes read, WRITE_SIZE is exact)
+FETCH_CORR, WRITE_CORR = 2.0, 1.0
+t["level4_4096"] = {"physics_bytes_per_launch": FETCH_CORR * val["FETCH_SIZE"] + WRITE_CORR * val["WRITE_SIZE"],
+                    "fetch_bytes": FETCH_CORR * val["FETCH_SIZE"], "write_bytes": WRITE_CORR * val["WRITE_SIZE"],
+                    "raw_counters_KB": {"FETCH_SIZE": val["FETCH_SIZE"] / 1024, "WRITE_SIZE": val["WRITE_SIZE"] / 1024},
+                    "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/{tag}_level4_pmc_summary.txt), KB * 1024, FETCH x 2 (gfx950 correction, "
+                            "calibrated with tools/probes/traffic_calib.hip: 131 082 KB reported for 262 144 KB read, WRITE exact). These are L2 <-> fabric requests and include "
+                            "Infinity-Cache hits: the 8 XCD L2s are not coherent with each other and start every launch cold, so each launch re-reads its state rows (1x) AND "
+                            "the 0.8 MB terrain table once per XCD (6.4 MB, the one-forward reset launch shows the same fixed 8 MB) from the Infinity Cache; writes are "
+                            "16-byte pieces of 128-byte lines per wave (4 envs per wave in the hex layout), counted as 64-byte requests"}
 json.dump(t, open(tp, "w"), indent=1)
 print("collected", tag, t["level4_4096"]["physics_bytes_per_launch"])
