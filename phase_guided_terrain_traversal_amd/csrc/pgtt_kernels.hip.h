@@ -256,6 +256,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   // 4 solver init x3 5 first gradient 6 line search 7 update_constraint 8 update_gradient 9 rest 10 #iterations
   if (e == PGTT_TIME && a.trace) {
     for (int i = 0; i < 20; i++) a.trace[i] = s.cyc[i];
+    for (int i = 20; i < 28; i++) a.trace[4 + i] = s.cyc[i];      // line-search sub-stages at [24..31]
     // whole-kernel span of this wave in shader-clock ticks and in ticks of the constant 100 MHz clock (gives the shader clock rate)
     a.trace[20] = (float)(__builtin_readcyclecounter() - t0_cyc); a.trace[21] = (float)(wall_clock64() - t0_real);
   }

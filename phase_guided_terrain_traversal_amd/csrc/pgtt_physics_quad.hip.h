@@ -182,12 +182,15 @@ struct QSim {
 #endif
 #ifdef PGTT_TIME
   // stage timer (-DPGTT_TIME builds): cyc[i] accumulates shader-clock ticks of stage i over the launch
-  long long tlast = 0; float cyc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = 0; float cyc[28] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 20..27: sub-stages of the line search (own clock)
+  long long tls = 0; PG_INL void ltick(int i) { long long t = __builtin_readcyclecounter(); cyc[i] += (float)(t - tls); tls = t; }
+#define PG_LTICK(sim, i) (sim).ltick(i)
   PG_INL void tick(int stage) { long long t = __builtin_readcyclecounter(); cyc[stage] += (float)(t - tlast); tlast = t; }
 #define PG_TICK(sim, stage) (sim).tick(stage)
   PG_INL void cyc_iter() { cyc[10] += 1.f; }
 #else
 #define PG_TICK(sim, stage) ((void)0)
+#define PG_LTICK(sim, i) ((void)0)
   PG_INL void cyc_iter() {}
 #endif
   // outputs
@@ -1038,6 +1041,7 @@ struct QSolver {
   // line search (ls_ja / ls_jv / ls_D, slot pairs (0,1) and (2,3)) - the Newton loop otherwise re-read ~100 LDS words per trip
   QContact mine; float mjar[4], mjv[4];
   f2 ls_ja[2], ls_jv[2], ls_D[2];
+  f2 qd_ja[4], qd_jv[4]; float qd_D[2];     // quad layout: rows of box slots 0, 1 for the current line search (row pairs 01, 23 of each)
   PG_INL bool own_on(int k) const { return (k < nslots) | (plane_sub & (k == 3)); }
   PG_INL bool own_any() const { return nslots > 0 || plane_sub; }
   bool any_lim, any_con0;   // wave-uniform: some lane has an active joint-limit row / an active plane contact.
@@ -1331,7 +1335,11 @@ struct QSolver {
         ls_row2<NA, COST>(f2{jar0[0], jar0[1]}, f2{jv0[0], jv0[1]}, s.con0.D, al, q);
         ls_row2<NA, COST>(f2{jar0[2], jar0[3]}, f2{jv0[2], jv0[3]}, s.con0.D, al, q);
       }
-      for (int k = 0; k < nslots; k++) {
+      // the rows of box slots 0 and 1 (all there is on the shipped terrains, bar a foot on a seam) were read from their LDS
+      // records once for this line search (qd_*): a round does not wait for an LDS round trip; slots 2, 3 are read in place
+      if (nslots > 0) { ls_row2<NA, COST>(qd_ja[0], qd_jv[0], qd_D[0], al, q); ls_row2<NA, COST>(qd_ja[1], qd_jv[1], qd_D[0], al, q); }
+      if (nslots > 1) { ls_row2<NA, COST>(qd_ja[2], qd_jv[2], qd_D[1], al, q); ls_row2<NA, COST>(qd_ja[3], qd_jv[3], qd_D[1], al, q); }
+      for (int k = 2; k < nslots; k++) {
         const float Dk = slots.at(k, 2);
         ls_row2<NA, COST>(f2{slots.jar(k, 0), slots.jar(k, 1)}, f2{slots.jv(k, 0), slots.jv(k, 1)}, Dk, al, q);
         ls_row2<NA, COST>(f2{slots.jar(k, 2), slots.jar(k, 3)}, f2{slots.jv(k, 2), slots.jv(k, 3)}, Dk, al, q);
@@ -1383,6 +1391,7 @@ struct QSolver {
   }
 
   PG_INL void linesearch(bool frozen) {
+    PG_LTICK(s, 27);
     float snb = 0.f, snl = 0.f;
 #pragma unroll
     for (int i = 0; i < 6; i++) snb += sb[i] * sb[i];
@@ -1417,6 +1426,15 @@ struct QSolver {
     if (plane_sub) {
 #pragma unroll
       for (int r = 0; r < 4; r++) jv0[r] = sub_bcast<3>(pv[r]);
+    }
+    if (kSubs == 1 && lds_slots) {
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const bool on = k < nslots;           // wave-uniform
+        qd_ja[2 * k] = f2{on ? slots.jar(k, 0) : 0.f, on ? slots.jar(k, 1) : 0.f}; qd_ja[2 * k + 1] = f2{on ? slots.jar(k, 2) : 0.f, on ? slots.jar(k, 3) : 0.f};
+        qd_jv[2 * k] = f2{on ? slots.jv(k, 0) : 0.f, on ? slots.jv(k, 1) : 0.f}; qd_jv[2 * k + 1] = f2{on ? slots.jv(k, 2) : 0.f, on ? slots.jv(k, 3) : 0.f};
+        qd_D[k] = on ? slots.at(k, 2) : 0.f;
+      }
     }
     if (kSubs == 4) {
       // pick by bit tests (selects, no branches): r = 0..3
@@ -1461,12 +1479,14 @@ struct QSolver {
       r.d1 = k3 ? c3.d1 : (k2 ? c2.d1 : (k1 ? c1.d1 : x.d1));
       return r;
     };
+    PG_LTICK(s, 20);      // set-up: M s, J s, row hand-over, Gauss coefficients
     LSPoint p0, lo0;
     { const float a0 = 0.f; ls_points<1>(&a0, jv_lim, jv0, qg0, qg1, qg2, &p0); }
     { const float a1 = p0.alpha - div_normal(p0.d0, p0.d1); ls_points<1>(&a1, jv_lim, jv0, qg0, qg1, qg2, &lo0); }
     bool lesser = lo0.d0 < p0.d0;
     LSPoint hi = lesser ? p0 : lo0, lo = lesser ? lo0 : p0;
     bool swap = true; int it = 0;
+    PG_LTICK(s, 21);      // the two initial points
     for (;;) {
       bool done = it >= m->ls_iterations || !swap || ((lo.d0 < 0.f) && (lo.d0 > -gtol)) || ((hi.d0 > 0.f) && (hi.d0 < gtol));
       if (__ballot(!done) == 0ull) break;
@@ -1482,12 +1502,14 @@ struct QSolver {
       const LSPoint nhi = tighten(hi, pt[1], pt[2], pt[0], mh);
       if (!done) { lo = nlo; hi = nhi; swap = ml | mh; it++; }
     }
+    PG_LTICK(s, 22);      // bracketing rounds
     {   // costs of the two points the bracket ended with
       const float al2[2] = {lo.alpha, hi.alpha};
       LSPoint fin[2];
       ls_points<2, true>(al2, jv_lim, jv0, qg0, qg1, qg2, fin);
       lo.cost = fin[0].cost; hi.cost = fin[1].cost;
     }
+    PG_LTICK(s, 23);      // final costs
     bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
     float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
     float ia = (improved && !frozen) ? alpha : 0.f;
@@ -1509,6 +1531,7 @@ struct QSolver {
         else { mjar[r] += mjv[r] * ia; slots.jar(k, r) = mjar[r]; }
       }
     }
+    PG_LTICK(s, 24);      // update of qacc, M qacc, J qacc - aref
   }
 
   PG_INL void solve() {

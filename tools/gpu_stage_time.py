@@ -15,16 +15,18 @@ env.reset(seed=1)
 L = native.lib(); L.pgtt_trace_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
 g = torch.Generator(device="cuda").manual_seed(0)
 names = ["position", "velocity", "constraint", "sensors", "solver init x2-3", "first gradient", "line search", "update_constraint", "update_gradient", "rest/integrate", "iterations", "  c: limits+plane", "  c: AABB pass 1a", "  c: narrow 1b", "  c: table+count 2a/2b", "  launch prologue", "  c: contact records", "-"]
-acc = np.zeros(22)
+acc = np.zeros(32)
 for k in range(60):
     act = torch.tanh(torch.randn(n, 12, device="cuda", generator=g) * 0.6)
     env.step(act)
     if k >= 20:
         buf = np.zeros(262144, np.float32); L.pgtt_trace_read(buf.ctypes.data, buf.size)
-        seg = buf.reshape(4, -1)[:, :22]
+        seg = buf.reshape(4, -1)[:, :32]
         acc += seg[(k + 2) % 4]           # reset issued launches 0 and 1; step k is launch k + 2, segment = launch % 4
 tot = acc[:10].sum()
 print(f"{wl} n={n}: mean Newton iterations per control step {acc[10] / 40:.2f} (4 substeps); line-search rounds per step executed by the wave {acc[18] / 40:.1f}, needed by env 0 {acc[19] / 40:.1f}")
 print(f"  whole kernel, this wave: {acc[20] / 40:.0f} shader ticks = {acc[21] / 40 * 10:.0f} ns -> shader clock {acc[20] / max(acc[21], 1) * 0.1:.2f} GHz")
 for i in list(range(10)) + list(range(11, 17)):
     print(f"  {names[i]:22s} {acc[i] / 40:12.0f} ticks/step  {100 * acc[i] / tot:5.1f} %")
+for i, nm in zip(range(24, 29), ("  ls: set-up (M s, J s, rows, Gauss terms)", "  ls: two initial points", "  ls: bracketing rounds", "  ls: final costs", "  ls: update")):
+    print(f"  {nm:42s} {acc[i] / 40:12.0f} ticks/step  {100 * acc[i] / tot:5.1f} %")
