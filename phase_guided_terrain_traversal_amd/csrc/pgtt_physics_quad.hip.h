@@ -1577,7 +1577,7 @@ struct QSolver {
 #pragma unroll
       for (int k = 0; k < 3; k++) gnl += gl[k] * gl[k];
       float gn = gnb + quad_sum(gnl);
-      bool done = niter >= m->iterations || ((prev_cost - cost) / scale < m->tolerance) || (sqrtf(gn) / scale < m->tolerance);
+      bool done = niter >= m->iterations || (div_normal(prev_cost - cost, scale) < m->tolerance) || (div_normal(sqrtf(gn), scale) < m->tolerance);
       if (__ballot(!done) == 0ull) break;
       PG_TICK(s, 9);
       linesearch(done);
