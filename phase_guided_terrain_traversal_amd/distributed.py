@@ -34,7 +34,20 @@ def init_from_env(backend: Optional[str] = None, force: bool = False) -> Tuple[i
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
+        if backend == "nccl":
+            # one process per GPU: bind the device BEFORE the communicator exists (RCCL otherwise guesses it at the first
+            # collective), and hand it to init_process_group so that barrier() / all_reduce run on it
+            if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
+                raise RuntimeError(f"rank {rank}: LOCAL_RANK {local} has no GPU (device_count = "
+                                   f"{torch.cuda.device_count() if torch.cuda.is_available() else 0})")
+            torch.cuda.set_device(local)
+            kw["device_id"] = torch.device("cuda", local)
+        try:
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        except TypeError:          # torch without the device_id argument
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world
 
 
