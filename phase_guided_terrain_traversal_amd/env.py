@@ -95,6 +95,21 @@ class Joystick:
     def config(self) -> Dict[str, Any]:
         return self._config
 
+    # go2/base.py:216-231 also exposes the compiled model and where it came from.  Here the "MuJoCo model" is the dict of compiled
+    # constants (mjcf.compile_mjcf of go2_mjx_feetonly.xml + scene, shipped as assets/go2_<task>.json), and its device form is the
+    # PgttModel struct the kernels read.
+    @property
+    def mj_model(self) -> Dict[str, Any]:
+        return self._model
+
+    @property
+    def mjx_model(self) -> "abi.PgttModel":
+        return self._ms
+
+    @property
+    def xml_path(self) -> str:
+        return mjcf.asset_path(self.task)
+
     @property
     def model(self) -> Dict[str, Any]:
         return self._model

@@ -502,6 +502,11 @@ def with_bias_velocity(model: Dict[str, Any], kv: float) -> Dict[str, Any]:
     return out
 
 
+def asset_path(task: str = "stairs") -> str:
+    """the shipped compiled-model asset of a task (the counterpart of go2_constants.task_to_xml, go2/go2_constants.py:45-52)"""
+    return os.path.join(_ASSET_DIR, {"flat_terrain": "go2_flat_terrain.json", "stairs": "go2_stairs.json"}[task])
+
+
 def load_model(task: str = "stairs") -> Dict[str, Any]:
     """Load the shipped, pre-compiled model constants (assets/go2_<task>.json).
 
