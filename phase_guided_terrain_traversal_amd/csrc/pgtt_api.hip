@@ -41,6 +41,7 @@ struct pgtt_env {
   PgttConfig* d_cfg = nullptr;
   PgttModel* d_model = nullptr;
   pgtt::TerrainBox* d_terrain = nullptr;
+  uint4* d_grid = nullptr; float grid_E = 1.f, grid_inv = 1.f;     // terrain grid of the collision pass (pgtt_physics_quad.hip.h::collide)
   int T = 0, B = 0;
   PgttBuffers buf{};
   bool bound = false;
@@ -79,7 +80,7 @@ namespace {
 
 pgtt::KArgs make_args(pgtt_env* h, const unsigned char* mask, float yaw_override) {
   pgtt::KArgs a;
-  a.model = h->d_model; a.cfg = h->d_cfg; a.terrain = h->d_terrain; a.T = h->T; a.B = h->B;
+  a.model = h->d_model; a.cfg = h->d_cfg; a.terrain = h->d_terrain; a.T = h->T; a.B = h->B; a.grid = h->d_grid; a.grid_E = h->grid_E; a.grid_inv = h->grid_inv;
   a.buf = h->buf; a.N = h->N; a.seed = h->seed; a.env_off = h->env_off; a.mask = mask; a.yaw_override = yaw_override; a.write_qpos = 0;
   a.rng_fix = h->test_rng_fix; a.scan_preset = h->test_scan_preset;
 #if defined(PGTT_TRACE) || defined(PGTT_TIME)
@@ -196,6 +197,7 @@ int pgtt_destroy(pgtt_handle h) {
   if (h->d_cfg) hipFree(h->d_cfg);
   if (h->d_model) hipFree(h->d_model);
   if (h->d_terrain) hipFree(h->d_terrain);
+  if (h->d_grid) hipFree(h->d_grid);
   for (int r = 0; r < pgtt_env::kRing; r++) for (int i = 0; i < 4; i++) if (h->ev[r][i]) hipEventDestroy(h->ev[r][i]);
   delete h;
   return PGTT_OK;
@@ -207,6 +209,7 @@ int pgtt_set_terrain(pgtt_handle h, const float* boxes, int T, int B) {
   if (T > 0 && (!boxes || B == 0)) return fail(PGTT_E_ARG, "pgtt_set_terrain: null table");
   HIP_TRY(hipSetDevice(h->device));
   if (h->d_terrain) { HIP_TRY(hipFree(h->d_terrain)); h->d_terrain = nullptr; }
+  if (h->d_grid) { HIP_TRY(hipFree(h->d_grid)); h->d_grid = nullptr; }
   h->T = 0; h->B = 0;
   if (T == 0) return PGTT_OK;
   std::vector<pgtt::TerrainBox> tab((size_t)T * B);
@@ -233,6 +236,33 @@ int pgtt_set_terrain(pgtt_handle h, const float* boxes, int T, int B) {
     t.hy = (std::fabs(t.m10) * r[7] + std::fabs(t.m11) * r[8] + std::fabs(t.m12) * r[9]) * 1.00001f + 1e-6f;
     t.hz = (std::fabs(t.m20) * r[7] + std::fabs(t.m21) * r[8] + std::fabs(t.m22) * r[9]) * 1.00001f + 1e-6f;
     t.pad = 0.f;
+  }
+  {
+    // Terrain grid: kGridG x kGridG cells over [-E, E]^2, E = the reach of the boxes that are actually placed (the unused
+    // placeholders of a variant are parked at ~(100 + k) m, terrain_scene_mjx.xml / terrain/generator.py:368-391).  Cell (ix, iy)
+    // holds the set of boxes whose world AABB, grown by the largest foot radius (+ slack for the rounding of the cell index),
+    // touches it; indices are clamped, so border cells reach to infinity and a parked box lands in a corner cell: the set of a
+    // foot's cell is a superset of the boxes whose grown AABB contains the foot centre, wherever the foot is.
+    const int G = pgtt::kGridG;
+    float rmax = 0.f;
+    for (int l = 0; l < PGTT_NLEG; l++) rmax = std::fmax(rmax, h->model.foot_radius[l]);
+    const float grow = rmax + 1e-5f + 1e-4f;
+    float E = 1.0f;
+    for (const auto& t : tab)
+      if (std::fabs(t.px) < 50.f && std::fabs(t.py) < 50.f) E = std::fmax(E, std::fmax(std::fabs(t.px) + t.hx, std::fabs(t.py) + t.hy) + grow);
+    const float inv = (float)G / (2.f * E);
+    std::vector<uint32_t> grid((size_t)T * G * G * 4, 0u);
+    auto cell_of = [&](float x) { int c = (int)std::floor((x + E) * inv); return c < 0 ? 0 : (c > G - 1 ? G - 1 : c); };
+    for (int v = 0; v < T; v++)
+      for (int b = 0; b < B; b++) {
+        const pgtt::TerrainBox& t = tab[(size_t)v * B + b];
+        const int x0 = cell_of(t.px - t.hx - grow), x1 = cell_of(t.px + t.hx + grow), y0 = cell_of(t.py - t.hy - grow), y1 = cell_of(t.py + t.hy + grow);
+        for (int iy = y0; iy <= y1; iy++)
+          for (int ix = x0; ix <= x1; ix++) grid[(((size_t)v * G + iy) * G + ix) * 4 + (b >> 5)] |= 1u << (b & 31);
+      }
+    HIP_TRY(hipMalloc(&h->d_grid, grid.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(h->d_grid, grid.data(), grid.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    h->grid_E = E; h->grid_inv = inv;
   }
   HIP_TRY(hipMalloc(&h->d_terrain, tab.size() * sizeof(pgtt::TerrainBox)));
   HIP_TRY(hipMemcpy(h->d_terrain, tab.data(), tab.size() * sizeof(pgtt::TerrainBox), hipMemcpyHostToDevice));

@@ -19,6 +19,8 @@ struct KArgs {
   const PgttModel* model;
   const PgttConfig* cfg;
   const TerrainBox* terrain;   // [T][B]
+  const uint4* grid;           // [T][kGridG * kGridG]: boxes whose grown world AABB touches the cell (bit b of the 128 = box b)
+  float grid_E, grid_inv;      // the grid covers [-E, E]^2, cell (ix, iy) = floor((x + E) * inv), clamped
   int T, B;
   PgttBuffers buf;
   int N;
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
     else s.ctrl[k] = S[(PGTT_S_QPOS + 7 + ac) * (long)N + e];          // mjx_env.init(ctrl = qpos[7:])
   }
   const TerrainBox* boxes = nullptr;
+  const uint4* grid_v = nullptr;
   int nbox = 0;
   // LDS staging of the env's terrain variant: centre + bounding radius of its <=100 boxes (read 2 x 4 substeps
   // by the broad phase), and a per-lane column for the broad-phase keys of the own foot
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   if (HAS_TERRAIN) {
     int v = a.buf.variant ? a.buf.variant[e] : 0;
     boxes = a.terrain + (long)v * a.B;
+    grid_v = a.grid + (long)v * (kGridG * kGridG);
     nbox = a.B;
     for (int b = threadIdx.x % (4 * kSubs); b < nbox; b += 4 * kSubs) {
       const TerrainBox* tb = boxes + b;
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
     PG_TICK(s, 9);
     ph.kinematics();
     PG_TICK(s, 0);
-    if (HAS_TERRAIN) ph.collide(boxes, nbox, sh_box, sh_box2, slots, quad); else s.nbox = 0;
+    if (HAS_TERRAIN) ph.collide(boxes, nbox, sh_box, sh_box2, slots, quad, grid_v, a.grid_E, a.grid_inv); else s.nbox = 0;
     PG_TICK(s, 16);
     ph.inertia();
     PG_TICK(s, 0);

@@ -98,6 +98,7 @@ template <int J> PG_INL float quad_bcast(float x) { return __int_as_float(quad_b
 #endif
 
 constexpr int kMaxB = 4;          // box contacts one foot can hold (= max_contact_points of the reference)
+constexpr int kGridG = 16;        // cells per side of the terrain grid (pgtt_set_terrain): 128-bit box mask per cell and variant
 constexpr int kMaxPenQ = 4;       // penetrating (foot, box) pairs tracked per foot
 
 struct QArrow { float bb[21]; float lb[18]; float ll[6]; };
@@ -681,7 +682,8 @@ struct QPhysics {
 
   // box collision detection of the own foot (needs the kinematic frames only): leaves, for each of the s.nbox selected
   // pairs, (dist, box, world contact point, world normal) in the slot record; constraint_stage() completes them
-  PG_INL void collide(const TerrainBox* __restrict__ boxes, int nbox, const float4* sh_box, const float2* sh_box2, const BoxSlots& slots, int quad) {
+  PG_INL void collide(const TerrainBox* __restrict__ boxes, int nbox, const float4* sh_box, const float2* sh_box2, const BoxSlots& slots, int quad,
+                      const uint4* __restrict__ grid, float grid_E, float grid_inv) {
     const float rad = m->foot_radius[l];
     s.nbox = 0;
     if (boxes == nullptr || nbox <= 0) return;
@@ -699,60 +701,39 @@ struct QPhysics {
     const int maxp = m->max_geom_pairs, maxc = m->max_contact_points;
     const bool broad = maxp > -1 && 4 * nbox > maxp;
     const float keyC = rad + m->box_rbound;
-    // pass 1a: own foot against every box of the variant, world-AABB test only (LDS-resident centres / extents).
-    //          Branch-free: the outcome of box b is bit b of a 128-bit per-lane mask, so the LDS reads pipeline.
+    // pass 1a: which boxes' world AABBs (grown by the foot radius) contain the own foot centre?  The terrain is static, so the
+    // host laid a kGridG x kGridG grid over the map once (pgtt_set_terrain): every cell holds the 128-bit set of boxes whose grown
+    // AABB touches it (border cells reach to infinity).  The foot's cell gives a small candidate set, and only those boxes go
+    // through the exact AABB test against the LDS-resident centres / extents - the outcome mask is identical to testing all
+    // boxes (the cell sets are supersets), at a few LDS rows per foot instead of one hundred.
     unsigned cm[4] = {0u, 0u, 0u, 0u};
     {
       const float pad = rad + 1e-5f;
       const float fx = s.footc.x, fy = s.footc.y, fz = s.footc.z;
-      if (kSubs == 1) {
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-          if (w * 32 >= nbox) break;                          // nbox is wave-uniform
-          unsigned bits = 0u;
-          const int left = nbox - w * 32 < 32 ? nbox - w * 32 : 32;   // valid boxes in this word (wave-uniform)
-          // batches of 8 boxes: enough LDS reads in flight, few enough not to be spilled.  The outcome is taken from
-          // the SIGN BIT of max_i(|d_i| - h_i) - pad (no compare -> no SGPR mask per box); `<` instead of `<=` is still
-          // a superset of the penetrating boxes (penetration needs |d_i| < h_i + rad < h_i + pad).  Rows >= nbox of
-          // the LDS tables are allocated but stale: the last batch may read them, their bits are cleared.
-          for (int j0 = 0; j0 < left; j0 += 8) {
-            unsigned byte = 0u;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-              const int b = w * 32 + j0 + j < PGTT_MAX_BOX ? w * 32 + j0 + j : PGTT_MAX_BOX - 1;
-              const float4 A = sh_box[b * kEnvsPerWave + quad];
-              const float2 H2 = sh_box2[b * kEnvsPerWave + quad];
-              const float ex = fabsf(A.x - fx) - A.w, ey = fabsf(A.y - fy) - H2.x, ez = fabsf(A.z - fz) - H2.y;
-              const float t = fmaxf(fmaxf(ex, ey), ez) - pad;
-              byte |= (__float_as_uint(t) >> 31) << j;
-            }
-            bits |= byte << j0;
-          }
-          if (left < 32) bits &= (1u << left) - 1u;
-          cm[w] = bits;
-        }
-      } else {
-        // hex layout: the boxes go round the four sub-lanes of the leg (box 32w + 4j + sub -> bit 4j + sub of word w:
-        // neighbouring sub-lanes read neighbouring LDS rows, no bank conflicts); an OR over the sub-lanes gives every
-        // lane the full mask
-        const int r = threadIdx.x & 3;
-#pragma unroll 1
-        for (int w = 0; w * 32 < nbox; w++) {               // nbox is wave-uniform; one batch of 8 LDS rows in flight
-          unsigned bits = 0u;
-#pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const int bx = w * 32 + 4 * j + r;
-            const int b = bx < PGTT_MAX_BOX ? bx : PGTT_MAX_BOX - 1;
-            const float4 A = sh_box[b * kEnvsPerWave + quad];
-            const float2 H2 = sh_box2[b * kEnvsPerWave + quad];
-            const float ex = fabsf(A.x - fx) - A.w, ey = fabsf(A.y - fy) - H2.x, ez = fabsf(A.z - fz) - H2.y;
-            const float t = fmaxf(fmaxf(ex, ey), ez) - pad;
-            bits |= (bx < nbox ? (__float_as_uint(t) >> 31) : 0u) << (4 * j);
-          }
-          const unsigned v = sub_or(bits << r);
-          cm[0] = w == 0 ? v : cm[0]; cm[1] = w == 1 ? v : cm[1]; cm[2] = w == 2 ? v : cm[2]; cm[3] = w == 3 ? v : cm[3];
-        }
+      const int ix = min(max((int)floorf((fx + grid_E) * grid_inv), 0), kGridG - 1), iy = min(max((int)floorf((fy + grid_E) * grid_inv), 0), kGridG - 1);
+      const uint4 cell = grid[iy * kGridG + ix];
+      // hex layout: sub-lane r tests the candidates with box index = r (mod 4); an OR over the sub-lanes gives every lane the mask
+      const unsigned own = kSubs == 1 ? 0xFFFFFFFFu : (0x11111111u << (threadIdx.x & 3));
+      unsigned cd[4] = {cell.x & own, cell.y & own, cell.z & own, cell.w & own};
+      for (;;) {
+        if (__ballot((cd[0] | cd[1] | cd[2] | cd[3]) != 0u) == 0ull) break;
+        const bool z0 = cd[0] == 0u, z1 = z0 & (cd[1] == 0u), z2 = z1 & (cd[2] == 0u);
+        const bool have = !(z2 & (cd[3] == 0u));
+        const int w = (int)z0 + (int)z1 + (int)z2;
+        const unsigned w23 = z2 ? cd[3] : cd[2], w12 = z1 ? w23 : cd[1], word = z0 ? w12 : cd[0];
+        const int bit = have ? (__ffs(word) - 1) : 0;
+        const unsigned one = have ? (1u << bit) : 0u;
+        cd[0] &= w == 0 ? ~one : ~0u; cd[1] &= w == 1 ? ~one : ~0u; cd[2] &= w == 2 ? ~one : ~0u; cd[3] &= w == 3 ? ~one : ~0u;
+        const int bx = w * 32 + bit;
+        const int b = bx < nbox ? bx : 0;
+        const float4 A = sh_box[b * kEnvsPerWave + quad];
+        const float2 H2 = sh_box2[b * kEnvsPerWave + quad];
+        const float ex = fabsf(A.x - fx) - A.w, ey = fabsf(A.y - fy) - H2.x, ez = fabsf(A.z - fz) - H2.y;
+        const float t = fmaxf(fmaxf(ex, ey), ez) - pad;
+        const unsigned hit = ((__float_as_uint(t) >> 31) != 0u && bx < nbox) ? one : 0u;
+        cm[0] |= w == 0 ? hit : 0u; cm[1] |= w == 1 ? hit : 0u; cm[2] |= w == 2 ? hit : 0u; cm[3] |= w == 3 ? hit : 0u;
       }
+      if (kSubs == 4) { cm[0] = sub_or(cm[0]); cm[1] = sub_or(cm[1]); cm[2] = sub_or(cm[2]); cm[3] = sub_or(cm[3]); }
     }
     PG_TICK(s, 12);
     // pass 1b: narrow phase on the candidates in box order (every lane pops its own lowest set bit); penetrating pairs kept
