@@ -1,0 +1,59 @@
+"""Distribution-level comparison with the reference's simulator: policy177's normaliser holds mean / std of the 215 privileged-observation
+rows over the 443 M samples of its training run (MJX).  Roll the same policy out here under the training conditions of its last
+curriculum stage (level13, full randomize.py DR, observation noise, the task's own command / gait-frequency sampling, AutoReset) and
+print both, block by block.      python tools/gpu_policy_stats.py [level13]      (GPU box)"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from phase_guided_terrain_traversal_amd import abi, configs, mjcf
+from phase_guided_terrain_traversal_amd.env import Joystick
+from phase_guided_terrain_traversal_amd.policy import load_policy
+from phase_guided_terrain_traversal_amd.randomize import domain_randomize
+
+BLOCKS = [("gyro", 0, 3), ("gravity", 3, 6), ("joint pos - default", 6, 18), ("joint vel", 18, 30), ("cos phase", 30, 34), ("sin phase", 34, 38),
+          ("scan - min", 38, 155), ("gait freq", 155, 156), ("last action", 156, 168), ("command", 168, 171), ("local linvel", 171, 174),
+          ("accelerometer", 174, 177), ("global angvel", 177, 180), ("actuator force", 180, 192), ("last contact", 192, 196),
+          ("feet linvel", 196, 208), ("feet air time", 208, 212)]
+
+
+def rollout_stats(level="level13", n=2048, steps=700, seed=0, dr=True):
+    assets = os.path.join(os.path.dirname(mjcf.__file__), "assets")
+    terrain = np.load(os.path.join(assets, "terrains", level + ".npy"))
+    model = mjcf.load_model("stairs")
+    kw = {}
+    if dr:
+        out = domain_randomize(model, n, seed=5, terrain=terrain)
+        kw = {"variant": torch.from_numpy(out["variant"]), "params": torch.from_numpy(out["params"]), "box_friction": torch.from_numpy(out["box_friction"])}
+    else:
+        kw["variant"] = torch.from_numpy(np.random.default_rng(2).integers(0, terrain.shape[0], n).astype(np.int32))
+    env = Joystick("stairs", configs.training_config(), num_envs=n, terrain=terrain, device="cuda:0", autoreset=True, **kw)
+    pi = load_policy("policy177")
+    env.reset(seed)
+    s1 = torch.zeros(abi.PRIV, device="cuda:0", dtype=torch.float64); s2 = torch.zeros_like(s1); cnt = 0
+    for k in range(steps):
+        env.step(pi(env.buffers["obs_state"]))
+        if k >= 100:
+            p = env.buffers["obs_priv"].double()
+            s1 += p.mean(0); s2 += (p * p).mean(0); cnt += 1
+    env.close()
+    mean = (s1 / cnt).cpu().numpy()
+    return mean, np.sqrt(np.maximum((s2 / cnt).cpu().numpy() - mean ** 2, 0))
+
+
+def compare(mean, std, ref_mean, ref_std):
+    rows = []
+    for name, a, b in BLOCKS:
+        rows.append(dict(block=name, mean_here=float(mean[a:b].mean()), mean_ref=float(ref_mean[a:b].mean()),
+                         std_here=float(std[a:b].mean()), std_ref=float(ref_std[a:b].mean()),
+                         mean_dev_sigma=float((np.abs(mean[a:b] - ref_mean[a:b]) / np.maximum(ref_std[a:b], 1e-6)).mean()),
+                         std_ratio=float((std[a:b] / np.maximum(ref_std[a:b], 1e-6)).mean())))
+    return rows
+
+
+if __name__ == "__main__":
+    level = sys.argv[1] if len(sys.argv) > 1 else "level13"
+    d = np.load(os.path.join(os.path.dirname(mjcf.__file__), "assets", "policies", "policy177.npz"))
+    mean, std = rollout_stats(level)
+    print(f"{'block':22s} {'mean here':>10s} {'mean ref':>10s} {'|dmean|/sigma':>13s} {'std here':>10s} {'std ref':>10s} {'std ratio':>10s}")
+    for r in compare(mean, std, d["mean_priv"], d["std_priv"]):
+        print(f"{r['block']:22s} {r['mean_here']:10.4f} {r['mean_ref']:10.4f} {r['mean_dev_sigma']:13.3f} {r['std_here']:10.4f} {r['std_ref']:10.4f} {r['std_ratio']:10.3f}")
