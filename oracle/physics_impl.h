@@ -424,6 +424,12 @@ static void F(sphere_box)(const R* spos, R radius, const R* bpos, const R* bmat,
   if (!inside) { pt[0] = ept[0]; pt[1] = ept[1]; pt[2] = ept[2]; }
   R n[3] = {pt[0] - c[0], pt[1] - c[1], pt[2] - c[2]};
   R dn = F(normalize_n)(n, 3);
+#ifndef PGTT_SPHERE_CONVEX_FLIP
+  /* centre INSIDE the box (deeper than one radius): keep the inward normal of the least-penetrated face and a growing depth.  The recalled
+     `normalize(pt - c)` would flip the frame and lose the contact; the reference's own training statistics (policy177's normaliser)
+     rule that out - see DESIGN.md 2 / 9.  -DPGTT_SPHERE_CONVEX_FLIP restores the recalled variant. */
+  if (FABS(c[0]) <= size[0] && FABS(c[1]) <= size[1] && FABS(c[2]) <= size[2]) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; dn = -dn; }
+#endif
   R spt[3] = {c[0] + n[0]*radius, c[1] + n[1]*radius, c[2] + n[2]*radius};
   *dist_out = dn - radius;
   R pl[3] = {(pt[0] + spt[0])*(R)0.5, (pt[1] + spt[1])*(R)0.5, (pt[2] + spt[2])*(R)0.5};

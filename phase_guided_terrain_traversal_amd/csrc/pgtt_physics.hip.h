@@ -206,6 +206,16 @@ PG_INL void sphere_box(V3 c_world, float radius, const TerrainBox& tb, float& di
   V3 ptv = v3(pt[0], pt[1], pt[2]);
   V3 n = ptv - c;
   float dn = normalize3(n);
+#ifndef PGTT_SPHERE_CONVEX_FLIP
+  // A sphere whose CENTRE is inside the box (penetration deeper than its radius) keeps the inward normal of the least-penetrated
+  // face and a depth that goes on growing.  The literal `n = normalize(pt - c)` of _sphere_convex as recalled would flip the frame there and drop
+  // the contact one radius further down - feet then fall through box tops at every hard landing (the 17.5 mm foot on this soft
+  // contact is pushed deeper than its radius at ~2 m/s).  The reference's own statistics rule that behaviour out: with the
+  // flip, policy177 tumbles on every stair level and its contact duty / tilt spread are 25 % / 130 % off the values its
+  // normaliser recorded over 443 M samples of MJX; without it they agree to 1 % / 8 % (tests/test_gpu_policy.py).
+  // -DPGTT_SPHERE_CONVEX_FLIP builds the recalled variant (oracle/Makefile has the same switch).
+  if ((fabsf(c.x) <= tb.sx) & (fabsf(c.y) <= tb.sy) & (fabsf(c.z) <= tb.sz)) { n = n * -1.0f; dn = -dn; }      // centre INSIDE the box
+#endif
   V3 spt = c + n * radius;
   dist = dn - radius;
   V3 pl = (ptv + spt) * 0.5f;

@@ -30,13 +30,24 @@ class PolicyMLP(torch.nn.Module):
             self.layers.append(lin)
 
     @torch.no_grad()
-    def forward(self, obs: torch.Tensor) -> torch.Tensor:
+    def head(self, obs: torch.Tensor) -> torch.Tensor:
         x = (obs - self.mean) / self.std
         for lin in self.layers[:-1]:
             x = torch.nn.functional.silu(lin(x))
-        x = self.layers[-1](x)
-        loc, _ = torch.chunk(x, 2, dim=-1)
+        return self.layers[-1](x)
+
+    @torch.no_grad()
+    def forward(self, obs: torch.Tensor) -> torch.Tensor:
+        loc, _ = torch.chunk(self.head(obs), 2, dim=-1)
         return torch.tanh(loc)
+
+    @torch.no_grad()
+    def sample(self, obs: torch.Tensor, generator=None) -> torch.Tensor:
+        """an action drawn from the policy's tanh-normal head as Brax's training rollouts draw it (scale = softplus(raw) + 1e-3):
+        the normaliser statistics of a reference policy were recorded under these stochastic actions, not under the mean"""
+        loc, raw = torch.chunk(self.head(obs), 2, dim=-1)
+        scale = torch.nn.functional.softplus(raw) + 1e-3
+        return torch.tanh(loc + scale * torch.randn(loc.shape, device=loc.device, dtype=loc.dtype, generator=generator))
 
 
 def load_policy(name: str = "policy177", device: str = "cuda:0") -> PolicyMLP:

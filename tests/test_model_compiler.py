@@ -160,7 +160,7 @@ def test_actuator_bias_velocity_gain_is_a_tested_switch():
     shortcut, go2/base.py:57-61 then overwrites gainprm[:,0] = Kp and biasprm[:,1] = -Kp.  The shipped constants keep
     biasprm[2] = -0.5 (actuator-level damping on top of the joint damping Kd); `compile_mjcf(..., keep_bias_velocity=False)` is
     the other reading of the shortcut (kv absent -> 0).  tests/test_gpu_policy.py::test_bias_velocity_switch_against_policy_statistics
-    shows which one reproduces the statistics recorded in the reference's own trained policy."""
+    shows which one reproduces the statistics recorded in the reference's own trained policy (the kept one, to 1-4 %)."""
     m = mjcf.load_model("stairs")
     assert np.allclose(m["act_bias"][:, 2], -0.5) and np.allclose(m["act_bias"][:, 0], 0.0)
     m0 = mjcf.with_bias_velocity(m, 0.0)

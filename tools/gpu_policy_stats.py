@@ -16,22 +16,29 @@ BLOCKS = [("gyro", 0, 3), ("gravity", 3, 6), ("joint pos - default", 6, 18), ("j
           ("feet linvel", 196, 208), ("feet air time", 208, 212)]
 
 
-def rollout_stats(level="level13", n=2048, steps=700, seed=0, dr=True):
+def rollout_stats(level="level13", n=2048, steps=700, seed=0, dr=True, stochastic=False, kv=None):
     assets = os.path.join(os.path.dirname(mjcf.__file__), "assets")
-    terrain = np.load(os.path.join(assets, "terrains", level + ".npy"))
-    model = mjcf.load_model("stairs")
-    kw = {}
-    if dr:
+    flat = level == "flat"
+    terrain = None if flat else np.load(os.path.join(assets, "terrains", level + ".npy"))
+    model = mjcf.load_model("flat_terrain" if flat else "stairs")
+    if kv is not None:
+        model = mjcf.with_bias_velocity(model, kv)
+    kw = {"model": model}
+    if dr and flat:
+        kw["params"] = torch.from_numpy(domain_randomize(model, n, seed=5)["params"])
+    elif flat:
+        pass
+    elif dr:
         out = domain_randomize(model, n, seed=5, terrain=terrain)
-        kw = {"variant": torch.from_numpy(out["variant"]), "params": torch.from_numpy(out["params"]), "box_friction": torch.from_numpy(out["box_friction"])}
+        kw.update(variant=torch.from_numpy(out["variant"]), params=torch.from_numpy(out["params"]), box_friction=torch.from_numpy(out["box_friction"]))
     else:
         kw["variant"] = torch.from_numpy(np.random.default_rng(2).integers(0, terrain.shape[0], n).astype(np.int32))
-    env = Joystick("stairs", configs.training_config(), num_envs=n, terrain=terrain, device="cuda:0", autoreset=True, **kw)
+    env = Joystick("flat_terrain" if flat else "stairs", configs.training_config(), num_envs=n, terrain=terrain, device="cuda:0", autoreset=True, **kw)
     pi = load_policy("policy177")
     env.reset(seed)
     s1 = torch.zeros(abi.PRIV, device="cuda:0", dtype=torch.float64); s2 = torch.zeros_like(s1); cnt = 0
     for k in range(steps):
-        env.step(pi(env.buffers["obs_state"]))
+        env.step(pi.sample(env.buffers["obs_state"]) if stochastic else pi(env.buffers["obs_state"]))
         if k >= 100:
             p = env.buffers["obs_priv"].double()
             s1 += p.mean(0); s2 += (p * p).mean(0); cnt += 1
@@ -52,8 +59,11 @@ def compare(mean, std, ref_mean, ref_std):
 
 if __name__ == "__main__":
     level = sys.argv[1] if len(sys.argv) > 1 else "level13"
+    use_dr = not (len(sys.argv) > 2 and sys.argv[2] == "nodr")
+    stoch = len(sys.argv) > 3 and sys.argv[3] == "stochastic"
+    kv = float(sys.argv[4]) if len(sys.argv) > 4 else None
     d = np.load(os.path.join(os.path.dirname(mjcf.__file__), "assets", "policies", "policy177.npz"))
-    mean, std = rollout_stats(level)
+    mean, std = rollout_stats(level, dr=use_dr, stochastic=stoch, kv=kv)
     print(f"{'block':22s} {'mean here':>10s} {'mean ref':>10s} {'|dmean|/sigma':>13s} {'std here':>10s} {'std ref':>10s} {'std ratio':>10s}")
     for r in compare(mean, std, d["mean_priv"], d["std_priv"]):
         print(f"{r['block']:22s} {r['mean_here']:10.4f} {r['mean_ref']:10.4f} {r['mean_dev_sigma']:13.3f} {r['std_here']:10.4f} {r['std_ref']:10.4f} {r['std_ratio']:10.3f}")
