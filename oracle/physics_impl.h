@@ -12,7 +12,11 @@
  *   go2/base.py:153-171          collision.geoms_colliding over data.contact
  *   go2/base.py:116-149          mjx_env.get_sensor_data (sensordata slices)
  * in the DENSE formulation MJX uses for nv=18 (<60 dofs => dense qM, dense efc_J, cho_factor).
- * It is pinned only by physics invariants and hand-derived KATs (tests/test_oracle_physics.py).
+ * It is pinned only by physics invariants and hand-derived KATs (tests/test_oracle_physics.py): no step-level vectors of the
+ * reference exist.  At DISTRIBUTION level the same arithmetic (through the HIP kernels, which this file checks step by step) is held
+ * to the reference's own simulator by the statistics its training run left in policy_folder/policy177's normaliser (443 M samples,
+ * 215 rows; tests/test_gpu_policy.py) - that evidence is what replaced the recalled frame flip of _sphere_convex
+ * for a sphere centre inside the box (sphere_box below).
  *
  * This header is included twice by pgtt_oracle.c: REAL=float (suffix _f32) and REAL=double (_f64).
  *
