@@ -189,6 +189,33 @@ def test_sphere_box_top_face_and_topk(model):
     assert np.allclose(d["con_frame"][k][0], [0, 0, -1], atol=1e-6)
 
 
+def test_sphere_box_keeps_its_frame_when_the_centre_is_inside(model):
+    """a foot sphere pushed deeper than its radius (centre below the box top): the contact keeps the inward normal of the
+    least-penetrated face and the depth goes on growing; a sphere wholly above / beside the box is no contact"""
+    m = f32_model("stairs")
+    ms = abi.model_struct(m)
+    q = m["key_qpos"].copy(); q[2] = 0.40                            # plane far below
+    feet = oracle.forward(ms, q, np.zeros(18), q[7:])["foot_xpos"]
+    r = 0.0175
+    boxes = np.tile(box_row([100, 100, 10], 0, [1, 1, 1]), (100, 1))
+    for k in range(100):
+        boxes[k, :3] = [100 + k, 100 + k, 10]
+    for depth in (0.005, 0.0175 + 0.006, 0.05):                      # sphere bottom 5 mm in; centre 6 mm below the top; centre 3.25 cm below
+        top = feet[0][2] - r + depth
+        boxes[5] = box_row([feet[0][0], feet[0][1], top / 2], 0.3, [0.4, 0.3, top / 2])
+        d = oracle.forward(ms, q, np.zeros(18), q[7:], boxes=boxes)
+        k = [i for i in range(4, 8) if d["con_box"][i] == 5 and d["con_foot"][i] == 0]
+        assert len(k) == 1
+        assert abs(d["con_dist"][k[0]] + depth) < 2e-6, (depth, d["con_dist"][k[0]])
+        assert np.allclose(d["con_frame"][k[0]][0], [0, 0, -1], atol=1e-6)      # from the sphere into the box, also with the centre inside
+        assert d["efc_force"][12 + 4 * k[0]:16 + 4 * k[0]].sum() > 0            # the pyramid pushes the foot OUT
+    # wholly above the box by 3 cm: the top face has no support and the remaining faces must not produce a contact
+    top = feet[0][2] - r - 0.03
+    boxes[5] = box_row([feet[0][0], feet[0][1], top / 2], 0.3, [0.4, 0.3, top / 2])
+    d = oracle.forward(ms, q, np.zeros(18), q[7:], boxes=boxes)
+    assert np.all(d["con_dist"][4:] > 0)
+
+
 def test_scan_matches_box_tops():
     m = f32_model("stairs")
     cs = abi.config_struct(configs.default_config())
