@@ -126,3 +126,25 @@ def test_per_row_statistics_pin_orderings_and_signs():
     assert np.abs(mean[208:212] / rm[208:212] - 1).max() < 0.04                          # mean air time per foot
     f, fr = mean[180:192], rm[180:192]
     assert np.array_equal(np.sign(f), np.sign(fr)) and np.abs(f - fr).max() < 0.1 * rs[180:192].max()
+
+
+def test_baseline_task_statistics_against_a_baseline_policy():
+    """N4, the comparison task go2/joystick.py (162 / 206 observations): policy_folder/policy175 is one of the reference's BASELINE
+    policies ("xx5": baseline, level3; 305 M samples).  Rolled out in the baseline env here (level2, full DR, sampled actions) it
+    reproduces its own normaliser: a different gait from the PGTT policies - contact duty 0.71 against 0.73 in the normaliser (0.44
+    for policy177) - with the spreads of the joint positions / velocities / last actions / actuator forces at 1.00 / 1.07 / 1.02 / 1.00
+    of the reference's.  (The air-time spread, 0.16 against 0.36, and the scan block depend on the early, stumbling stages of that
+    training run and on its level mixture; they are not asserted.)"""
+    import numpy as np
+    from gpu_policy_stats import BLOCKS_BASELINE, compare, rollout_stats
+    from phase_guided_terrain_traversal_amd import mjcf
+    d = np.load(os.path.join(os.path.dirname(mjcf.__file__), "assets", "policies", "policy175.npz"))
+    assert d["mean"].shape == (162,) and d["mean_priv"].shape == (206,)
+    mean, std = rollout_stats("level2", n=2048, steps=1200, stochastic=True, policy="policy175", method="baseline")
+    rows = {r["block"]: r for r in compare(mean, std, d["mean_priv"], d["std_priv"], BLOCKS_BASELINE)}
+    for r in rows.values():
+        print(r)
+    for name in ("joint pos - default", "joint vel", "last action", "actuator force", "gyro", "global angvel", "feet linvel"):
+        assert rows[name]["mean_dev_sigma"] < 0.25 and 0.88 < rows[name]["std_ratio"] < 1.15, rows[name]
+    assert abs(rows["last contact"]["mean_here"] - rows["last contact"]["mean_ref"]) < 0.04
+    assert 0.8 < rows["accelerometer"]["std_ratio"] < 1.1 and 0.9 < rows["gravity"]["std_ratio"] < 1.25

@@ -16,7 +16,13 @@ BLOCKS = [("gyro", 0, 3), ("gravity", 3, 6), ("joint pos - default", 6, 18), ("j
           ("feet linvel", 196, 208), ("feet air time", 208, 212)]
 
 
-def rollout_stats(level="level13", n=2048, steps=700, seed=0, dr=True, stochastic=False, kv=None):
+BLOCKS_BASELINE = [("gyro", 0, 3), ("gravity", 3, 6), ("joint pos - default", 6, 18), ("joint vel", 18, 30), ("scan - min", 30, 147),
+                   ("last action", 147, 159), ("command", 159, 162), ("local linvel", 162, 165), ("accelerometer", 165, 168),
+                   ("global angvel", 168, 171), ("actuator force", 171, 183), ("last contact", 183, 187), ("feet linvel", 187, 199),
+                   ("feet air time", 199, 203)]
+
+
+def rollout_stats(level="level13", n=2048, steps=700, seed=0, dr=True, stochastic=False, kv=None, policy="policy177", method="pgtt"):
     assets = os.path.join(os.path.dirname(mjcf.__file__), "assets")
     flat = level == "flat"
     terrain = None if flat else np.load(os.path.join(assets, "terrains", level + ".npy"))
@@ -33,10 +39,10 @@ def rollout_stats(level="level13", n=2048, steps=700, seed=0, dr=True, stochasti
         kw.update(variant=torch.from_numpy(out["variant"]), params=torch.from_numpy(out["params"]), box_friction=torch.from_numpy(out["box_friction"]))
     else:
         kw["variant"] = torch.from_numpy(np.random.default_rng(2).integers(0, terrain.shape[0], n).astype(np.int32))
-    env = Joystick("flat_terrain" if flat else "stairs", configs.training_config(), num_envs=n, terrain=terrain, device="cuda:0", autoreset=True, **kw)
-    pi = load_policy("policy177")
+    env = Joystick("flat_terrain" if flat else "stairs", configs.training_config(method), num_envs=n, terrain=terrain, device="cuda:0", autoreset=True, **kw)
+    pi = load_policy(policy)
     env.reset(seed)
-    s1 = torch.zeros(abi.PRIV, device="cuda:0", dtype=torch.float64); s2 = torch.zeros_like(s1); cnt = 0
+    s1 = torch.zeros(env.observation_size["privileged_state"], device="cuda:0", dtype=torch.float64); s2 = torch.zeros_like(s1); cnt = 0
     for k in range(steps):
         env.step(pi.sample(env.buffers["obs_state"]) if stochastic else pi(env.buffers["obs_state"]))
         if k >= 100:
@@ -47,9 +53,9 @@ def rollout_stats(level="level13", n=2048, steps=700, seed=0, dr=True, stochasti
     return mean, np.sqrt(np.maximum((s2 / cnt).cpu().numpy() - mean ** 2, 0))
 
 
-def compare(mean, std, ref_mean, ref_std):
+def compare(mean, std, ref_mean, ref_std, blocks=None):
     rows = []
-    for name, a, b in BLOCKS:
+    for name, a, b in (blocks or BLOCKS):
         rows.append(dict(block=name, mean_here=float(mean[a:b].mean()), mean_ref=float(ref_mean[a:b].mean()),
                          std_here=float(std[a:b].mean()), std_ref=float(ref_std[a:b].mean()),
                          mean_dev_sigma=float((np.abs(mean[a:b] - ref_mean[a:b]) / np.maximum(ref_std[a:b], 1e-6)).mean()),
