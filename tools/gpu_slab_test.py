@@ -1,3 +1,5 @@
+"""Does a foot stand ON a box?  policy177 walks onto one wide slab of a given height; prints the steady trunk / foot heights over the slab
+against the flat-ground values (the experiment behind the sphere-box fix)."""
 import os, sys
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
 import numpy as np, torch

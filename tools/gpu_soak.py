@@ -1,3 +1,5 @@
+"""Soak: tens of thousands of control steps with random actions, auto-reset and full DR on both layouts; every buffer is checked for
+non-finite values and the termination rate is printed."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from phase_guided_terrain_traversal_amd import configs, abi

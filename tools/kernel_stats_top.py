@@ -1,3 +1,4 @@
+"""Top rows of a rocprofv3 --kernel-trace --stats output directory:  python tools/kernel_stats_top.py gpurun_out/<dir>"""
 import csv,glob,sys
 f=glob.glob(sys.argv[1]+"/**/*kernel_stats.csv",recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
