@@ -21,10 +21,25 @@ from dataclasses import dataclass
 from typing import Callable, Dict, Optional
 
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import abi
+
+
+def _world():
+    """(world size, rank) of the data-parallel job; (1, 0) without a process group."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def _dp() -> bool:
+    """Are the data-parallel code paths (all-reduces of gradients / statistics / logs) active?  Always with more than one rank;
+    PGTT_PPO_FORCE_DP=1 switches them on for a ONE-rank process group too - the collectives are then identities through RCCL,
+    which is how a single-GPU box runs exactly the code an 8-GPU job runs (tests/test_gpu_train.py)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("PGTT_PPO_FORCE_DP", "0") == "1")
 
 
 class RunningNorm:
@@ -42,9 +57,22 @@ class RunningNorm:
         x = x.reshape(-1, x.shape[-1])
         n = x.shape[0]
         ones = torch.ones(1, n, device=x.device, dtype=x.dtype)
-        mean_b = (ones @ x).squeeze(0) / n
-        xc = x - mean_b
-        batch_m2 = (ones @ (xc * xc)).squeeze(0)
+        if _dp():
+            # data parallel (brax running_statistics.update with pmap_axis_name: the step's moments are psum-ed): the batch
+            # is the union of the ranks' shards (equal heights: ppo.train gives every rank the same number of envs) - its
+            # mean from one all-reduce of the column sums, its squared deviations about THAT mean from a second one (no raw
+            # sums of squares in fp32); every rank ends with the same statistics
+            col = (ones @ x).squeeze(0)
+            dist.all_reduce(col)
+            n = n * _world()[0]
+            mean_b = col / n
+            xc = x - mean_b
+            batch_m2 = (ones @ (xc * xc)).squeeze(0)
+            dist.all_reduce(batch_m2)
+        else:
+            mean_b = (ones @ x).squeeze(0) / n
+            xc = x - mean_b
+            batch_m2 = (ones @ (xc * xc)).squeeze(0)
         new_count = self.count + n
         delta = mean_b - self.mean
         w = (self.count * n / new_count).to(x.dtype)
@@ -253,14 +281,22 @@ class _Learner:
         self.idx = torch.zeros(mb, dtype=torch.long, device=B["obs"].device)
         self.loss = torch.zeros((), device=B["obs"].device)
         self.use_graph, self.graph, self.calls = use_graph, None, 0
+        # data parallel (one process per GPU; brax pmean-s the gradients over its devices): ONE flat fp32 bucket with every
+        # gradient of both MLPs (0.53 M floats = 2.1 MB), one RCCL all-reduce per minibatch update.  The update's backward is
+        # ~1 ms of launch-bound small kernels and the ring all-reduce of 2.1 MB over xGMI some tens of us, so the bucket is
+        # not split to overlap with the backward.
+        self.world, self.dp = _world()[0], _dp()
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), device=B["obs"].device) if self.dp else None
         # the value branch (its own MLP, its own inputs) runs on a side stream next to the policy branch, forward and - since
         # autograd replays a node on the stream of its forward - backward: the ~150 launches of an update are 4-30 us each
         # and launch-latency bound, two independent chains overlap
-        self.side = torch.cuda.Stream(device=B["obs"].device) if os.environ.get("PGTT_PPO_STREAMS", "2") == "2" else None
+        self.side = (torch.cuda.Stream(device=B["obs"].device)
+                     if B["obs"].is_cuda and os.environ.get("PGTT_PPO_STREAMS", "2") == "2" else None)
 
     def _loss(self):
         """policy part of the loss: fused HIP kernel (PGTT_PPO_FUSED=0: the PyTorch-op form below)"""
-        if os.environ.get("PGTT_PPO_FUSED", "1") == "0":
+        if os.environ.get("PGTT_PPO_FUSED", "1") == "0" or not self.B["obs"].is_cuda:
             return self._loss_torch()
         B, idx, cfg, model = self.B, self.idx, self.cfg, self.model
         out = model.policy(self.norm_s(B["obs"][idx]))
@@ -296,13 +332,30 @@ class _Learner:
         main.wait_stream(self.side)
         return pol + v_loss
 
-    def _eager(self):
-        self.opt.zero_grad(set_to_none=True)
+    def _forward_backward(self):
         loss = self._total_loss()
         loss.backward()
+        self.loss.copy_(loss.detach())
+        if self.dp:                        # pack every gradient into the one bucket the all-reduce works on
+            torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
+
+    def _all_reduce(self):
+        if self.dp:
+            dist.all_reduce(self.flat)
+
+    def _apply(self):
+        if self.dp:                        # mean of the ranks' gradients back into .grad, then the same clip + Adam in every rank
+            self.flat.mul_(1.0 / self.world)
+            grads = [p.grad for p in self.params]
+            torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(self.flat.split([g.numel() for g in grads]), grads)])
         nn.utils.clip_grad_norm_(self.model.parameters(), self.cfg.max_grad_norm)
         self.opt.step()
-        self.loss.copy_(loss.detach())
+
+    def _eager(self):
+        self.opt.zero_grad(set_to_none=True)
+        self._forward_backward()
+        self._all_reduce()
+        self._apply()
 
     def update(self, idx):
         self.idx.copy_(idx)
@@ -311,32 +364,53 @@ class _Learner:
             try:
                 dev = self.idx.device
                 torch.cuda.synchronize(dev)
-                g = torch.cuda.CUDAGraph()
                 self.opt.zero_grad(set_to_none=True)
-                with torch.cuda.graph(g):
-                    self._eager_body_for_capture()
-                self.graph = g
+                if not self.dp:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._forward_backward()
+                        self._apply()
+                    self.graph = (g,)
+                else:
+                    # the collective stays OUTSIDE the captured work: forward / backward / pack is one graph, unpack / clip / Adam
+                    # a second one in the same memory pool (the gradients the first allocates are read by the second), the
+                    # all-reduce an ordinary RCCL call between the two replays
+                    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(ga):
+                        self._forward_backward()
+                    with torch.cuda.graph(gb, pool=ga.pool()):
+                        self._apply()
+                    self.graph = (ga, gb)
             except Exception as exc:
+                if self.dp:                 # a rank that alone drops to eager launches would still issue the same collectives,
+                    raise                   # but a half-captured state is not worth continuing from in a multi-rank job
                 print(f"[ppo] HIP graph capture of the update failed ({exc}); running eagerly")
                 self.use_graph = False
         if self.graph is not None:
-            self.graph.replay()
+            self.graph[0].replay()
+            if self.dp:
+                self._all_reduce()
+                self.graph[1].replay()
         else:
             self._eager()
         return self.loss
 
-    def _eager_body_for_capture(self):
-        loss = self._total_loss()
-        loss.backward()
-        nn.utils.clip_grad_norm_(self.model.parameters(), self.cfg.max_grad_norm)
-        self.opt.step()
-        self.loss.copy_(loss.detach())
-
 
 def train(env, cfg: PPOConfig, progress_fn: Optional[Callable[[int, Dict[str, float]], bool]] = None,
           policy_params_fn: Optional[Callable[[int, Dict], None]] = None, restore: Optional[Dict] = None, use_graph: bool = True):
-    """PPO on a `Joystick` env created with autoreset=True.  Returns (model, normalisers, metrics history)."""
-    dev = env.device
+    """PPO on a `Joystick` env created with autoreset=True.  Returns (model, normalisers, metrics history).
+
+    Data parallel when a `torch.distributed` process group exists (one process per GPU, `torchrun train.py ...`): `env` is this
+    rank's shard of the envs, `cfg.batch_size` the GLOBAL minibatch height (brax divides num_envs and batch_size by its device
+    count the same way), every rank collects its own rollout and runs the same number of minibatch updates on 1 / world of
+    each minibatch; gradients are averaged (one flat RCCL all-reduce per update), the observation statistics and the
+    logged episode sums are summed over ranks, and every rank holds the same weights at every step.  `progress_fn` runs in
+    every rank on identical numbers (its early-stop decision must not differ between ranks), `policy_params_fn` in rank 0."""
+    dev = torch.device(env.device)
+    on_gpu = dev.type == "cuda"
+    use_graph = use_graph and on_gpu
+    sync = (lambda: torch.cuda.synchronize(dev)) if on_gpu else (lambda: None)
+    (world, rank), dp = _world(), _dp()
     n = env.num_envs
     torch.manual_seed(cfg.seed)
     od, pd = env.observation_size["state"], env.observation_size["privileged_state"]
@@ -346,14 +420,20 @@ def train(env, cfg: PPOConfig, progress_fn: Optional[Callable[[int, Dict[str, fl
         model.load_state_dict(restore["model"])
         for nm, st in ((norm_s, restore["norm_state"]), (norm_p, restore["norm_priv"])):
             nm.count.copy_(st["count"].to(dev)); nm.mean.copy_(st["mean"].to(dev)); nm.m2.copy_(st["m2"].to(dev))
+    if dp:
+        for t in list(model.parameters()) + [norm_s.count, norm_s.mean, norm_s.m2, norm_p.count, norm_p.mean, norm_p.m2]:
+            dist.broadcast(t.data, src=0)                         # one set of initial weights whatever the ranks' generators did
+        if rank > 0:                                              # ... and independent exploration / minibatch noise per rank
+            torch.manual_seed(cfg.seed + 1_000_003 * rank)        # (rank 0 keeps the stream a single-process run has)
     try:        # one fused multi-tensor Adam launch instead of ~10 foreach launches per update
-        opt = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate, capturable=use_graph, fused=True)
+        opt = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate, capturable=use_graph, fused=on_gpu)
     except (RuntimeError, TypeError):
         opt = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate, capturable=use_graph)
-    assert (cfg.batch_size * cfg.num_minibatches) % n == 0, "batch_size * num_minibatches must be a multiple of num_envs"
-    unrolls = cfg.batch_size * cfg.num_minibatches // n
+    assert (cfg.batch_size * cfg.num_minibatches) % (n * world) == 0, \
+        "batch_size * num_minibatches must be a multiple of the total number of envs (num_envs per rank x world size)"
+    unrolls = cfg.batch_size * cfg.num_minibatches // (n * world)
     T = unrolls * cfg.unroll_length
-    steps_per_iter = T * n
+    steps_per_iter = T * n * world                                # env-steps of the whole job per iteration
     iters = max(1, math.ceil(cfg.num_timesteps / steps_per_iter))
     eval_every = max(1, iters // max(cfg.num_evals - 1, 1))
     L = env.config["episode_length"]
@@ -378,7 +458,7 @@ def train(env, cfg: PPOConfig, progress_fn: Optional[Callable[[int, Dict[str, fl
             # 0; value targets vs = acc + V, advantages = (r + gamma (1 - term) vs[t+1] - V) (1 - trunc) with vs[T] = V(last obs)
             adv, ret = compute_gae(batch["trunc"], batch["done"] * (1.0 - batch["trunc"]), batch["rew"], values[:-1], values[-1],
                                    cfg.gae_lambda, cfg.discounting)
-        torch.cuda.synchronize(dev); t1 = time.perf_counter(); t_env += t1 - t0
+        sync(); t1 = time.perf_counter(); t_env += t1 - t0
         flat = lambda x: x.reshape(T * n, *x.shape[2:])
         if learner is None:
             B = {k: flat(batch[k]) for k in ("obs", "priv", "u", "logp")}          # views of the actor's static storage
@@ -390,19 +470,29 @@ def train(env, cfg: PPOConfig, progress_fn: Optional[Callable[[int, Dict[str, fl
             perm = torch.randperm(T * n, device=dev)
             for k in range(cfg.num_minibatches):
                 loss = learner.update(perm[k * mb:(k + 1) * mb])
-        torch.cuda.synchronize(dev); t_sgd += time.perf_counter() - t1
+        sync(); t_sgd += time.perf_counter() - t1
         env_steps += steps_per_iter
         if (it + 1) % eval_every == 0 or it == iters - 1:
-            c = max(float(ep_cnt), 1.0)
-            m = {"eval/episode_reward": float(ep_ret_sum) / c, "eval/avg_episode_length": float(ep_len_sum) / c,
-                 "episodes": float(ep_cnt), "env_steps_per_s_rollout": (it + 1) * steps_per_iter / max(t_env, 1e-9),
-                 "env_steps_per_s_total": (it + 1) * steps_per_iter / max(t_env + t_sgd, 1e-9),
-                 "loss": float(loss.detach()), "mean_step_reward": float(batch["rew"].mean())}
+            # one fused buffer: [episode return sum, length sum, count, 22 metric sums, loss, mean step reward, t_env, t_sgd],
+            # summed over the ranks (the last four then divided by the world size) - every rank reports the same numbers
+            log = torch.cat([torch.stack([ep_ret_sum, ep_len_sum, ep_cnt]), ep_metric_sum,
+                             torch.stack([loss.detach().reshape(()), batch["rew"].mean()]),
+                             torch.tensor([t_env, t_sgd], device=dev, dtype=ep_ret_sum.dtype)])
+            if dp:
+                dist.all_reduce(log)
+                log[3 + abi.NMETRIC:] /= world
+            log = log.tolist()
+            c = max(log[2], 1.0)
+            te, ts = (log[-2], log[-1]) if dp else (t_env, t_sgd)
+            m = {"eval/episode_reward": log[0] / c, "eval/avg_episode_length": log[1] / c,
+                 "episodes": log[2], "env_steps_per_s_rollout": (it + 1) * steps_per_iter / max(te, 1e-9),
+                 "env_steps_per_s_total": (it + 1) * steps_per_iter / max(te + ts, 1e-9),
+                 "loss": log[3 + abi.NMETRIC], "mean_step_reward": log[4 + abi.NMETRIC]}
             for i, k in enumerate(abi.REWARD_KEYS):
-                m[f"eval/episode_reward/{k}"] = float(ep_metric_sum[i]) / c
+                m[f"eval/episode_reward/{k}"] = log[3 + i] / c
             history.append((env_steps, m))
             ep_ret_sum.zero_(); ep_len_sum.zero_(); ep_cnt.zero_(); ep_metric_sum.zero_()
-            if policy_params_fn is not None:
+            if policy_params_fn is not None and rank == 0:
                 policy_params_fn(env_steps, checkpoint(model, norm_s, norm_p))
             if progress_fn is not None and progress_fn(env_steps, m):
                 break

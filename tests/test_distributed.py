@@ -125,3 +125,94 @@ def test_bench_refuses_fewer_gpus_than_asked():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--steps", "2", "--warmup", "1"],
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
+
+
+PPO_WORKER = r'''
+import os, sys, json, hashlib
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from phase_guided_terrain_traversal_amd import abi, ppo
+from phase_guided_terrain_traversal_amd.distributed import init_from_env
+rank, local, world = init_from_env("gloo")
+
+
+class StubEnv:
+    """The attributes ppo.train uses of a Joystick env, on CPU tensors: observations are a fixed random projection of a per-env
+    state, the reward prefers actions near a linear function of the observation, episodes end at random."""
+    def __init__(self, n, offset):
+        self.num_envs, self.device, self.offset = n, torch.device("cpu"), offset
+        self.observation_size = {"state": abi.OBS, "privileged_state": abi.PRIV}
+        self.config = {"episode_length": 12}
+        g = torch.Generator().manual_seed(5)
+        self.Ws, self.Wp, self.Wa = torch.randn(6, abi.OBS, generator=g), torch.randn(6, abi.PRIV, generator=g), torch.randn(6, abi.NU, generator=g) * 0.3
+        self.buffers = {"obs_state": torch.zeros(n, abi.OBS), "obs_priv": torch.zeros(n, abi.PRIV), "frame": torch.ones(abi.F_UPVECTOR + 3, n),
+                        "istate": torch.zeros(abi.I_EP_STEPS + 1, n, dtype=torch.int32)}
+        self.epm = torch.zeros(abi.NMETRIC + 2, n)
+    def _obs(self):
+        return {"state": self.buffers["obs_state"], "privileged_state": self.buffers["obs_priv"]}
+    def _refresh(self):
+        self.buffers["obs_state"].copy_(self.x @ self.Ws + 3.0 * (1 + self.offset)); self.buffers["obs_priv"].copy_(self.x @ self.Wp)
+    def reset(self, seed=0):
+        self.g = torch.Generator().manual_seed(100 + seed + self.offset)
+        self.x = torch.randn(self.num_envs, 6, generator=self.g); self._refresh()
+        return self._obs()
+    def step(self, act):
+        reward = 1.0 - ((act - torch.tanh(self.x @ self.Wa)) ** 2).mean(1)
+        self.x = 0.9 * self.x + 0.3 * torch.randn(self.num_envs, 6, generator=self.g)
+        I = self.buffers["istate"]; I[abi.I_EP_STEPS] += 1
+        done = ((torch.rand(self.num_envs, generator=self.g) < 0.05) | (I[abi.I_EP_STEPS] >= 12)).float()
+        self.epm[abi.NMETRIC] += reward; self.epm[abi.NMETRIC + 1] += 1; self.epm[0] += reward
+        info = {"episode_metrics": self.epm.clone()}
+        self.epm *= (1 - done); I[abi.I_EP_STEPS] *= (1 - done).int()
+        self._refresh()
+        return self._obs(), reward, done, info
+
+
+env = StubEnv(8, offset=8 * rank)
+cfg = ppo.PPOConfig(num_timesteps=3 * 5 * 8 * world, num_evals=3, unroll_length=5, num_minibatches=4, batch_size=4, num_updates_per_batch=2, seed=3)
+seen = []
+model, (ns, np_), hist = ppo.train(env, cfg, progress_fn=lambda s, m: seen.append(s) and False, policy_params_fn=lambda s, p: seen.append(("ckpt", s)), use_graph=False)
+h = hashlib.sha256()
+for t in list(model.state_dict().values()) + [ns.count, ns.mean, ns.m2, np_.count, np_.mean, np_.m2]:
+    h.update(t.detach().cpu().numpy().tobytes())
+# the normaliser against ONE process fed the union of the shards
+torch.manual_seed(0)
+xs = [torch.randn(40, 7) * (1 + r) + r for r in range(world)]
+a = ppo.RunningNorm(7, "cpu"); a.update(xs[rank]); a.update(xs[rank] * 2)
+lone = {}
+print(json.dumps({"rank": rank, "hash": h.hexdigest(), "count": float(ns.count), "hist": [[s, m["eval/episode_reward"], m["episodes"], m["loss"]] for s, m in hist],
+                  "seen": [str(x) for x in seen], "norm_mean": a.mean.tolist(), "norm_std": a.std.tolist(), "norm_count": float(a.count),
+                  "state_mean0": float(ns.mean[0])}))
+dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_ppo_world2_gloo(tmp_path):
+    """Two ranks, each with its own shard of (stub) envs: identical weights and observation statistics in both ranks after training
+    (gradient all-reduce, summed normaliser moments), global step / episode accounting, checkpoints from rank 0 only."""
+    import json
+    import torch
+    from phase_guided_terrain_traversal_amd import ppo
+    script = tmp_path / "ppo_worker.py"
+    script.write_text(PPO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    a, b = sorted(outs, key=lambda o: o["rank"])
+    assert a["hash"] == b["hash"]                                  # bit-identical weights and statistics in both ranks
+    assert a["hist"] == b["hist"] and len(a["hist"]) == 3          # same logged numbers, three evaluations
+    assert [h[0] for h in a["hist"]] == [80, 160, 240]             # env-steps count the whole job: 5 steps x 8 envs x 2 ranks per iteration
+    assert a["count"] == 240.0                                     # the normaliser saw both shards
+    assert 13.0 < a["state_mean0"] < 17.0                          # ... whose observation offsets are 3 and 27: 15 +- x @ Ws, not either shard's own
+    assert sum(s.startswith("('ckpt'") for s in a["seen"]) == 3 and not any(s.startswith("('ckpt'") for s in b["seen"])
+    torch.manual_seed(0)
+    xs = [torch.randn(40, 7) * (1 + r) + r for r in range(2)]
+    ref = ppo.RunningNorm(7, "cpu"); ref.update(torch.cat(xs)); ref.update(torch.cat(xs) * 2)
+    for o in (a, b):
+        assert o["norm_count"] == 160.0
+        assert np.allclose(o["norm_mean"], ref.mean.numpy(), atol=1e-5) and np.allclose(o["norm_std"], ref.std.numpy(), rtol=1e-5)

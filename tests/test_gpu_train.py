@@ -87,3 +87,45 @@ def test_long_batch_linear_backward_matches_autograd(shape):
     for name, ra, rb in (("dx", xa.grad, xb.grad), ("dw", lin_a.weight.grad, lin_b.weight.grad), ("db", lin_a.bias.grad, lin_b.bias.grad)):
         scale = float(ra.abs().max())
         assert float((ra - rb).abs().max()) < 2e-5 * scale * (K ** 0.5) / 10 + 1e-6, (name, float((ra - rb).abs().max()), scale)
+
+
+def test_data_parallel_update_path_through_rccl_single_rank():
+    """The data-parallel trainer on this box's one GPU: a one-rank RCCL process group with PGTT_PPO_FORCE_DP=1 runs exactly what an
+    8-GPU job runs per rank (packed gradient bucket -> RCCL all-reduce between the two captured graphs of an update -> unpack, clip,
+    Adam; all-reduced observation statistics and logs).  With one rank every collective is an identity, so the run must reproduce
+    the plain single-process run (same seed, same envs) - which it does to the last bit unless the split capture reorders something."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from phase_guided_terrain_traversal_amd import configs, ppo
+from phase_guided_terrain_traversal_amd.distributed import init_from_env
+from phase_guided_terrain_traversal_amd.env import Joystick
+rank, local, world = init_from_env("nccl", force=True)
+assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+out = {}
+for mode in ("0", "1"):
+    os.environ["PGTT_PPO_FORCE_DP"] = mode
+    assert ppo._dp() == (mode == "1")
+    env = Joystick("flat_terrain", configs.training_config(), num_envs=1024, device="cuda:0", autoreset=True)
+    cfg = ppo.PPOConfig(num_timesteps=4 * 20 * 8192, num_evals=3, seed=5)
+    model, (ns, npv), hist = ppo.train(env, cfg)
+    torch.cuda.synchronize()
+    out[mode] = (torch.cat([p.detach().reshape(-1) for p in model.parameters()] + [ns.mean, ns.m2, npv.mean, npv.m2]).cpu(), hist)
+    env.close()
+a, b = out["0"][0], out["1"][0]
+print(json.dumps({"max_diff": float((a - b).abs().max()), "scale": float(a.abs().max()), "finite": bool(torch.isfinite(b).all()),
+                  "steps": [s for s, _ in out["1"][1]], "len0": out["0"][1][-1][1]["eval/avg_episode_length"], "len1": out["1"][1][-1][1]["eval/avg_episode_length"],
+                  "sps": out["1"][1][-1][1]["env_steps_per_s_total"], "sps_plain": out["0"][1][-1][1]["env_steps_per_s_total"]}))
+dist.destroy_process_group()
+""" % root
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29643", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.strip().splitlines() if l.startswith("{")][-1])
+    print(r)
+    assert r["finite"] and r["steps"][-1] == 4 * 20 * 8192
+    assert r["max_diff"] <= 1e-5 * max(r["scale"], 1.0)
+    assert r["sps"] > 0.7 * r["sps_plain"]            # the eager all-reduce between two graph replays costs little
