@@ -11,17 +11,20 @@
 
 #include "pgtt_kernels.hip.h"
 
-// the physics_kernel instantiations (2 lane layouts x step/forward x DR x terrain) live in their own translation units
+// the physics_kernel instantiations (3 lane layouts x step/forward x DR x terrain) live in their own translation units
 // (pgtt_physics_inst.hip, compiled in parallel); this file only sees their host launchers
 #define PG_DECL(S, M, D, T) void pgtt_launch_physics_s##S##_##M##_##D##_##T(int nblocks, hipStream_t st, const pgtt::KArgs& a, const float* action);
 #define PG_DECL8(S) PG_DECL(S, 0, 0, 0) PG_DECL(S, 0, 0, 1) PG_DECL(S, 0, 1, 0) PG_DECL(S, 0, 1, 1) PG_DECL(S, 1, 0, 0) PG_DECL(S, 1, 0, 1) PG_DECL(S, 1, 1, 0) PG_DECL(S, 1, 1, 1)
-PG_DECL8(1) PG_DECL8(4)
+PG_DECL8(1) PG_DECL8(2) PG_DECL8(4)
 #undef PG_DECL8
 #undef PG_DECL
 
 namespace {
 
 thread_local std::string g_err;
+
+// the oct layout (8 envs per wave) keeps one wave per SIMD up to this batch
+constexpr int kOctMaxEnvs = 8192;
 
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
@@ -109,17 +112,20 @@ void launch_physics(pgtt_env* h, const pgtt::KArgs& a_in, const float* action, h
   // quad layout: 16 envs per 64-thread block; hex layout: 4 envs per block (pgtt_physics_quad.hip.h)
   const bool dr = h->buf.params != nullptr, terr = h->T > 0;
   typedef void (*launcher)(int, hipStream_t, const pgtt::KArgs&, const float*);
-  static const launcher table[2][2][2][2] = {
+  static const launcher table[3][2][2][2] = {
       {{{pgtt_launch_physics_s1_0_0_0, pgtt_launch_physics_s1_0_0_1}, {pgtt_launch_physics_s1_0_1_0, pgtt_launch_physics_s1_0_1_1}},
        {{pgtt_launch_physics_s1_1_0_0, pgtt_launch_physics_s1_1_0_1}, {pgtt_launch_physics_s1_1_1_0, pgtt_launch_physics_s1_1_1_1}}},
       {{{pgtt_launch_physics_s4_0_0_0, pgtt_launch_physics_s4_0_0_1}, {pgtt_launch_physics_s4_0_1_0, pgtt_launch_physics_s4_0_1_1}},
-       {{pgtt_launch_physics_s4_1_0_0, pgtt_launch_physics_s4_1_0_1}, {pgtt_launch_physics_s4_1_1_0, pgtt_launch_physics_s4_1_1_1}}}};
-  // auto: the hex layout has the shorter instruction stream (line-search rows, Cholesky columns and - on box terrain - the
-  // collision passes and contact slots are split over the sub-lanes) but four times the waves; it wins while those still
-  // run concurrently, one per SIMD (<= 1024 waves): level4 0.21 ms against 0.39 ms, flat ground 0.137 ms against 0.141 ms
-  const bool hex = h->layout == 4 || (h->layout == 0 && h->N <= 4096);
-  const int per = hex ? 4 : 16;
-  table[hex ? 1 : 0][MODE][dr ? 1 : 0][terr ? 1 : 0]((h->N + per - 1) / per, st, a, action);
+       {{pgtt_launch_physics_s4_1_0_0, pgtt_launch_physics_s4_1_0_1}, {pgtt_launch_physics_s4_1_1_0, pgtt_launch_physics_s4_1_1_1}}},
+      {{{pgtt_launch_physics_s2_0_0_0, pgtt_launch_physics_s2_0_0_1}, {pgtt_launch_physics_s2_0_1_0, pgtt_launch_physics_s2_0_1_1}},
+       {{pgtt_launch_physics_s2_1_0_0, pgtt_launch_physics_s2_1_0_1}, {pgtt_launch_physics_s2_1_1_0, pgtt_launch_physics_s2_1_1_1}}}};
+  // auto: a launch lasts as long as one wave's instruction stream while all its waves run concurrently, one per SIMD (<= 1024
+  // waves), and the stream is the shorter the more lanes share an env: hex (4 envs per wave: line-search rows, Cholesky columns
+  // and - on box terrain - the collision passes and contact slots split over four sub-lanes) up to 4096 envs (level4 0.18 ms
+  // against 0.39 ms in the quad layout, flat ground 0.137 against 0.141 ms), oct (8 envs per wave) up to 8192, quad beyond
+  const int subs = h->layout != 0 ? h->layout : (h->N <= 4096 ? 4 : (h->N <= kOctMaxEnvs ? 2 : 1));
+  const int per = 16 / subs;
+  table[subs == 1 ? 0 : (subs == 4 ? 1 : 2)][MODE][dr ? 1 : 0][terr ? 1 : 0]((h->N + per - 1) / per, st, a, action);
 }
 
 template <int OMODE>
@@ -172,9 +178,9 @@ int pgtt_create(const PgttConfig* cfg, const PgttModel* model, int device, int n
   pgtt_env* h = new pgtt_env();
   h->device = device; h->N = num_envs; h->cfg = *cfg; h->model = *model;
   {
-    // lane layout: PGTT_LAYOUT=quad|hex forces one; default by batch size
+    // lane layout: PGTT_LAYOUT=quad|oct|hex forces one; default by batch size
     const char* lay = getenv("PGTT_LAYOUT");
-    h->layout = (lay && !strcmp(lay, "hex")) ? 4 : ((lay && !strcmp(lay, "quad")) ? 1 : 0);
+    h->layout = (lay && !strcmp(lay, "hex")) ? 4 : ((lay && !strcmp(lay, "oct")) ? 2 : ((lay && !strcmp(lay, "quad")) ? 1 : 0));
     // observe as one kernel (every wave repeats the per-env scalar half: faster while the batch leaves SIMDs idle) or
     // PGTT_OBSERVE=split: scan + observation rows (env per wave) and rewards / bookkeeping (env per lane) as two kernels.
     // The fused kernel (four waves per SIMD since its reward terms are evaluated lane-parallel) is faster at every batch

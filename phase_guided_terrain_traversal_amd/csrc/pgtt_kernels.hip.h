@@ -86,9 +86,9 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
 #ifdef PGTT_TIME
   const long long t0_cyc = __builtin_readcyclecounter(), t0_real = wall_clock64();
 #endif
-  const int l = (threadIdx.x / kSubs) & 3;             // leg FL,FR,RL,RR
+  const int l = lane_leg();                            // leg FL,FR,RL,RR
   const int blk = xcd_block(blockIdx.x, gridDim.x);
-  int e = blk * kEnvsPerWave + (threadIdx.x / (4 * kSubs));
+  int e = blk * kEnvsPerWave + lane_env();
   bool valid = e < N;
   if (!valid) e = N - 1;                               // keep whole quads running (DPP), suppress the stores
   if (MODE != MODE_STEP && a.mask && !a.mask[e]) valid = false;
@@ -126,14 +126,14 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   __shared__ float4 sh_box[HAS_TERRAIN ? PGTT_MAX_BOX * kEnvsPerWave : 1];      // (cx, cy, cz, hx)
   __shared__ float2 sh_box2[HAS_TERRAIN ? PGTT_MAX_BOX * kEnvsPerWave : 1];     // (hy, hz)
   __shared__ float sh_con[HAS_TERRAIN ? kMaxB * kSlotFields * kSlotCols : 1];
-  const int quad = threadIdx.x / (4 * kSubs);          // env within the wave
-  const BoxSlots slots{sh_con, (int)threadIdx.x / kSubs};
+  const int quad = lane_env();                         // env within the wave
+  const BoxSlots slots{sh_con, lane_col()};
   if (HAS_TERRAIN) {
     int v = a.buf.variant ? a.buf.variant[e] : 0;
     boxes = a.terrain + (long)v * a.B;
     grid_v = a.grid + (long)v * (kGridG * kGridG);
     nbox = a.B;
-    for (int b = threadIdx.x % (4 * kSubs); b < nbox; b += 4 * kSubs) {
+    for (int b = lane_in_env(); b < nbox; b += 4 * kSubs) {
       const TerrainBox* tb = boxes + b;
       sh_box[b * kEnvsPerWave + quad] = make_float4(tb->px, tb->py, tb->pz, tb->hx);
       sh_box2[b * kEnvsPerWave + quad] = make_float2(tb->hy, tb->hz);
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   QSolver sol(m, s, slots);
   sol.lds_slots = HAS_TERRAIN && nbox > 0;
 #ifdef PGTT_TRACE
-  if (valid && e == 0 && a.trace && threadIdx.x % kSubs == 0) s.tr = a.trace + l;
+  if (valid && e == 0 && a.trace && lane_sub() == 0) s.tr = a.trace + l;
 #endif
   const int nsub = MODE == MODE_STEP ? cfg->n_substeps : 1;
   const float dt = m->timestep;

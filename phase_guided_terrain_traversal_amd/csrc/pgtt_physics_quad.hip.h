@@ -23,12 +23,24 @@ namespace pgtt {
 //                       leg's state replicated (bit-identical) and split selected loops among themselves (constraint
 //                       rows of the line search / Hessian, boxes of the collision passes).  A launch lasts as long as
 //                       one wave's instruction stream, so for small batches the shorter stream wins.
-// "quad_*" primitives act over the four LEGS of an env, "sub_*" over the four sub-lanes of a leg.
+//   PG_SUBS = 2  "oct" : lane = 16*row + 4*leg + 2*env_in_row + sub   8 envs per wave (two per 16-lane DPP row, interleaved
+//                       so that the legs of an env are 4 lanes apart exactly as in the hex layout and its two sub-lanes are
+//                       neighbours).  Two sub-lanes per leg split the row pairs of the line search and the boxes of the
+//                       collision passes; everything else follows the quad layout's per-leg code, done twice.  It is the
+//                       layout for 4097..8192 envs: 1024 waves, still one per SIMD.
+// "quad_*" primitives act over the four LEGS of an env, "sub_*" over the sub-lanes of a leg.
 #ifndef PG_SUBS
 #define PG_SUBS 1
 #endif
 constexpr int kSubs = PG_SUBS;
 constexpr int kEnvsPerWave = 16 / PG_SUBS;
+static_assert(PG_SUBS == 1 || PG_SUBS == 2 || PG_SUBS == 4, "lane layouts: quad, oct, hex");
+// who am I: sub-lane of the leg, leg of the env, env of the wave, lane of the env, LDS column of the (env, leg) pair
+PG_INL int lane_sub() { return kSubs == 4 ? (int)(threadIdx.x & 3) : (kSubs == 2 ? (int)(threadIdx.x & 1) : 0); }
+PG_INL int lane_leg() { return kSubs == 1 ? (int)(threadIdx.x & 3) : (int)((threadIdx.x >> 2) & 3); }
+PG_INL int lane_env() { return kSubs == 1 ? (int)(threadIdx.x >> 2) : (kSubs == 4 ? (int)(threadIdx.x >> 4) : (int)(2 * (threadIdx.x >> 4) + ((threadIdx.x >> 1) & 1))); }
+PG_INL int lane_in_env() { return kSubs == 2 ? 2 * lane_leg() + lane_sub() : (int)(threadIdx.x % (4 * kSubs)); }
+PG_INL int lane_col() { return kSubs == 2 ? 4 * lane_env() + lane_leg() : (int)(threadIdx.x / kSubs); }
 template <int CTRL>
 PG_INL float dpp_f(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
@@ -52,28 +64,35 @@ PG_INL float quad_sum(float x) {
 }
 PG_INL int quad_sum_i(int x) { x += dpp_i<kLegStep1>(x); x += dpp_i<kLegStep2>(x); return x; }
 PG_INL V3 quad_sum(V3 a) { return v3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)); }
-// sum over the four sub-lanes of a leg (hex layout; identity in the quad layout)
+// sum over the sub-lanes of a leg (four in the hex layout, two neighbours in the oct layout; identity in the quad layout)
 PG_INL float sub_sum(float x) {
-#if PG_SUBS == 4
 #pragma clang fp contract(off)
+#if PG_SUBS >= 2
   x = x + dpp_f<0xB1>(x);
+#endif
+#if PG_SUBS == 4
   x = x + dpp_f<0x4E>(x);
 #endif
   return x;
 }
 PG_INL int sub_sum_i(int x) {
-#if PG_SUBS == 4
+#if PG_SUBS >= 2
   x += dpp_i<0xB1>(x);
+#endif
+#if PG_SUBS == 4
   x += dpp_i<0x4E>(x);
 #endif
   return x;
 }
-// value held by sub-lane Q of the own leg (hex layout)
-template <int Q> PG_INL int sub_bcast(int x) { return PG_SUBS == 4 ? dpp_i<Q * 0x55>(x) : x; }
-template <int Q> PG_INL float sub_bcast(float x) { return PG_SUBS == 4 ? dpp_f<Q * 0x55>(x) : x; }
+// value held by sub-lane Q of the own leg (hex: quad_perm [Q,Q,Q,Q]; oct, Q < 2: quad_perm [Q,Q,2+Q,2+Q])
+constexpr int sub_bcast_ctrl(int q) { return PG_SUBS == 4 ? q * 0x55 : ((q & 1) ? 0xF5 : 0xA0); }
+template <int Q> PG_INL int sub_bcast(int x) { return PG_SUBS >= 2 ? dpp_i<sub_bcast_ctrl(Q)>(x) : x; }
+template <int Q> PG_INL float sub_bcast(float x) { return PG_SUBS >= 2 ? dpp_f<sub_bcast_ctrl(Q)>(x) : x; }
 PG_INL unsigned sub_or(unsigned x) {
-#if PG_SUBS == 4
+#if PG_SUBS >= 2
   x |= (unsigned)dpp_i<0xB1>((int)x);
+#endif
+#if PG_SUBS == 4
   x |= (unsigned)dpp_i<0x4E>((int)x);
 #endif
   return x;
@@ -232,7 +251,7 @@ PG_INL void qarrow_factor(QArrow& A) {
   const float i22 = __builtin_amdgcn_rsqf(c[5] - l20 * l20 - l21 * l21);
   c[0] = i00; c[1] = l10; c[2] = i11; c[3] = l20; c[4] = l21; c[5] = i22;
   float* w = A.lb;
-  if (kSubs == 1) {
+  if (kSubs != 4) {
 #pragma unroll
     for (int k = 0; k < 6; k++) {
       float w0 = w[k] * i00;
@@ -413,7 +432,7 @@ struct QPhysics {
     s.qb[3] = q0.w; s.qb[4] = q0.x; s.qb[5] = q0.y; s.qb[6] = q0.z;
     s.p0 = v3(s.qb[0], s.qb[1], s.qb[2]);
     s.R0 = qmat(q0);
-    if (kSubs == 1) body_inertia(0, s.p0, q0, em.base_ipos, em.mass0, xi0, Iw0);
+    if (kSubs != 4) body_inertia(0, s.p0, q0, em.base_ipos, em.mass0, xi0, Iw0);
     s.imu = s.p0 + qrot(v3(m->imu_pos[0], m->imu_pos[1], m->imu_pos[2]), q0);
     V3 pp = s.p0; Q4 pq = q0;
     V3 lpos[3]; Q4 lq[3];          // link frames (hex layout: the world inertias are formed afterwards, one body per sub-lane)
@@ -427,7 +446,7 @@ struct QPhysics {
       s.axis[k] = qrot(ax, pq);
       s.anchor[k] = pos;
       Q4 xq = qmul(pq, Q4{cs, ax.x * sn, ax.y * sn, ax.z * sn});
-      if (kSubs == 1) body_inertia(mb, pos, xq, v3(m->body_ipos[mb][0], m->body_ipos[mb][1], m->body_ipos[mb][2]), em.massl[k], xil[k], Iwl[k]);
+      if (kSubs != 4) body_inertia(mb, pos, xq, v3(m->body_ipos[mb][0], m->body_ipos[mb][1], m->body_ipos[mb][2]), em.massl[k], xil[k], Iwl[k]);
       lpos[k] = pos; lq[k] = xq;
       pp = pos; pq = xq;
     }
@@ -661,8 +680,8 @@ struct QPhysics {
     mix(m->foot_solref, m->foot_solimp, m->foot_solmix, m->box_solref, m->box_solimp, m->box_solmix, sr, si);
     float margin = fmaxf(m->foot_margin, m->box_margin) - fmaxf(m->foot_gap, m->box_gap);
 #pragma unroll
-    for (int k0 = 0; k0 < (kSubs == 1 ? kMaxB : 1); k0++) {
-      const int k = kSubs == 1 ? k0 : (int)(threadIdx.x & 3);        // hex: sub-lane k completes slot k, in one pass
+    for (int k0 = 0; k0 < (kSubs != 4 ? kMaxB : 1); k0++) {
+      const int k = kSubs != 4 ? k0 : (int)(threadIdx.x & 3);        // hex: sub-lane k completes slot k, in one pass
       if (__ballot(k < s.nbox) == 0ull) break;
       if (k < s.nbox) {
         QContact cc;
@@ -713,7 +732,7 @@ struct QPhysics {
       const int ix = min(max((int)floorf((fx + grid_E) * grid_inv), 0), kGridG - 1), iy = min(max((int)floorf((fy + grid_E) * grid_inv), 0), kGridG - 1);
       const uint4 cell = grid[iy * kGridG + ix];
       // hex layout: sub-lane r tests the candidates with box index = r (mod 4); an OR over the sub-lanes gives every lane the mask
-      const unsigned own = kSubs == 1 ? 0xFFFFFFFFu : (0x11111111u << (threadIdx.x & 3));
+      const unsigned own = kSubs == 1 ? 0xFFFFFFFFu : (kSubs == 4 ? (0x11111111u << (threadIdx.x & 3)) : (0x55555555u << (threadIdx.x & 1)));
       unsigned cd[4] = {cell.x & own, cell.y & own, cell.z & own, cell.w & own};
       for (;;) {
         if (__ballot((cd[0] | cd[1] | cd[2] | cd[3]) != 0u) == 0ull) break;
@@ -733,7 +752,7 @@ struct QPhysics {
         const unsigned hit = ((__float_as_uint(t) >> 31) != 0u && bx < nbox) ? one : 0u;
         cm[0] |= w == 0 ? hit : 0u; cm[1] |= w == 1 ? hit : 0u; cm[2] |= w == 2 ? hit : 0u; cm[3] |= w == 3 ? hit : 0u;
       }
-      if (kSubs == 4) { cm[0] = sub_or(cm[0]); cm[1] = sub_or(cm[1]); cm[2] = sub_or(cm[2]); cm[3] = sub_or(cm[3]); }
+      if (kSubs > 1) { cm[0] = sub_or(cm[0]); cm[1] = sub_or(cm[1]); cm[2] = sub_or(cm[2]); cm[3] = sub_or(cm[3]); }
     }
     PG_TICK(s, 12);
     // pass 1b: narrow phase on the candidates in box order (every lane pops its own lowest set bit); penetrating pairs kept
@@ -770,6 +789,9 @@ struct QPhysics {
       const int r = threadIdx.x & 3;
       if (kSubs == 1) {
         b = pop();
+      } else if (kSubs == 2) {
+        const int b0 = pop(), b1 = pop();                           // oct layout: the next two candidates, one per sub-lane
+        b = (threadIdx.x & 1) ? b1 : b0;
       } else {
         // hex layout: the next four candidates go to the four sub-lanes (the mask is replicated, so every sub-lane pops
         // all four and keeps its own)
@@ -786,6 +808,11 @@ struct QPhysics {
       if (kSubs == 1) {
         if ((pp.dist < 0.f) & (npen < kMaxPenQ)) park(npen, pw, nw);
         keep(pp);
+      } else if (kSubs == 2) {
+        QPen g0{sub_bcast<0>(pp.dist), sub_bcast<0>(pp.key), sub_bcast<0>(pp.idx)}, g1{sub_bcast<1>(pp.dist), sub_bcast<1>(pp.key), sub_bcast<1>(pp.idx)};
+        const int before = ((threadIdx.x & 1) && g0.dist < 0.f) ? 1 : 0;
+        if ((pp.dist < 0.f) & (npen + before < kMaxPenQ)) park(npen + before, pw, nw);
+        keep(g0); keep(g1);
       } else {
         // every lane appends the four results in candidate (= box index) order, as the sequential loop would; the
         // sub-lane that computed a penetrating pair parks its point / normal at the entry the pair is going to take
@@ -828,7 +855,7 @@ struct QPhysics {
       int cnt = 0;
       static_assert(PGTT_MAX_BOX <= 128, "hex layout: the <= 32 boxes of a sub-lane are one mask word");
 #pragma unroll 4
-      for (int t = 0, b = (kSubs == 1 ? 0 : (int)(threadIdx.x & 3)); b < nbox; t++, b += kSubs) {     // hex: boxes go round the sub-lanes
+      for (int t = 0, b = lane_sub(); b < nbox; t++, b += kSubs) {     // hex / oct: boxes go round the sub-lanes
         const float4 A = sh_box[b * kEnvsPerWave + quad];
         V3 dv = v3(A.x, A.y, A.z) - s.footc;
         const bool in = dot(dv, dv) <= thr2;
@@ -874,6 +901,16 @@ struct QPhysics {
           const int bn = b + 1 < PGTT_MAX_BOX ? b + 1 : b;       // next row, read while this one is ranked (rows >= nbox: stale, unused)
           An = sh_box[bn * kEnvsPerWave + quad];
           rank_against(packed(norm(v3(A.x, A.y, A.z) - s.footc) - keyC, l * nbox + b));
+        }
+      } else if (kSubs == 2) {
+        // oct layout: even boxes in sub-lane 0, odd ones in sub-lane 1 (an odd box count leaves sub-lane 1 a last turn without a box)
+#pragma unroll 1
+        for (int b0 = 0; b0 < nbox; b0 += 2) {
+          const int b = b0 + (int)(threadIdx.x & 1);
+          const bool have = b < nbox;
+          const float4 A = sh_box[(have ? b : 0) * kEnvsPerWave + quad];
+          const unsigned long long pk = packed(norm(v3(A.x, A.y, A.z) - s.footc) - keyC, l * nbox + b);
+          rank_against(have ? pk : ~0ull);
         }
       } else {
         // hex layout: only the own boxes that pass 2a found at least as close as the farthest candidate can sort before a
@@ -947,7 +984,7 @@ struct QPhysics {
       return okm & (beat < nslot);
     };
     int nb = 0;
-    if (kSubs == 1) {
+    if (kSubs != 4) {
       bool mine[kMaxPenQ];
 #pragma unroll
       for (int i = 0; i < kMaxPenQ; i++) {
@@ -1023,6 +1060,9 @@ struct QSolver {
   QContact mine; float mjar[4], mjv[4];
   f2 ls_ja[2], ls_jv[2], ls_D[2];
   f2 qd_ja[4], qd_jv[4]; float qd_D[2];     // quad layout: rows of box slots 0, 1 for the current line search (row pairs 01, 23 of each)
+  // oct layout: sub-lane 0 evaluates the row pair (0, 1), sub-lane 1 the pair (2, 3) of every constraint of the leg - limit rows
+  // (0, 1) / (2, -), the plane contact, box slot k (qd_ja[k] / qd_jv[k] then hold the OWN pair of slot k) - picked once per search
+  f2 oc_lim_ja, oc_lim_jv, oc_lim_D, oc_pl_ja, oc_pl_jv; float oc_D[4];
   PG_INL bool own_on(int k) const { return (k < nslots) | (plane_sub & (k == 3)); }
   PG_INL bool own_any() const { return nslots > 0 || plane_sub; }
   bool any_lim, any_con0;   // wave-uniform: some lane has an active joint-limit row / an active plane contact.
@@ -1081,10 +1121,10 @@ struct QSolver {
       for (int r = 0; r < 4; r++) jar0[r] = (s.con0.row_active ? jx[r] : 0.f) - s.con0.aref[r];
     }
     float pv[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < (kSubs == 1 ? nslots : (own_any() ? 1 : 0)); k0++) {
-      const int k = kSubs == 1 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
+    for (int k0 = 0; k0 < (kSubs != 4 ? nslots : (own_any() ? 1 : 0)); k0++) {
+      const int k = kSubs != 4 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
       if (!own_on(k)) continue;
-      const QContact cn = kSubs == 1 ? slots.load(k) : mine;
+      const QContact cn = kSubs != 4 ? slots.load(k) : mine;
       float jx[4];
       con_jx(cn, tw, jx);
 #pragma unroll
@@ -1124,7 +1164,7 @@ struct QSolver {
       F.l = F.l + fw; F.a = F.a + cross(cn.off, fw);
     };
     if (any_con0 && !plane_sub) add_contact(s.con0, jar0, Fs, csum);
-    if (kSubs == 1) {
+    if (kSubs != 4) {
       for (int k = 0; k < nslots; k++) {
         const QContact cn = slots.load(k);
         float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
@@ -1243,7 +1283,7 @@ struct QSolver {
       }
     };
     if (any_con0 && !plane_sub) add_hessian(s.con0, jar0, Gbb, H.lb, H.ll);
-    if (kSubs == 1) {
+    if (kSubs != 4) {
       for (int k = 0; k < nslots; k++) {
         const QContact cn = slots.load(k);
         float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
@@ -1325,6 +1365,13 @@ struct QSolver {
         ls_row2<NA, COST>(f2{slots.jar(k, 0), slots.jar(k, 1)}, f2{slots.jv(k, 0), slots.jv(k, 1)}, Dk, al, q);
         ls_row2<NA, COST>(f2{slots.jar(k, 2), slots.jar(k, 3)}, f2{slots.jv(k, 2), slots.jv(k, 3)}, Dk, al, q);
       }
+    } else if (kSubs == 2) {
+      if (any_lim) ls_row2d<NA, COST>(oc_lim_ja, oc_lim_jv, oc_lim_D, al, q);
+      if (any_con0) ls_row2<NA, COST>(oc_pl_ja, oc_pl_jv, s.con0.D, al, q);
+      if (nslots > 0) ls_row2<NA, COST>(qd_ja[0], qd_jv[0], oc_D[0], al, q);
+      if (nslots > 1) ls_row2<NA, COST>(qd_ja[1], qd_jv[1], oc_D[1], al, q);
+      if (nslots > 2) ls_row2<NA, COST>(qd_ja[2], qd_jv[2], oc_D[2], al, q);
+      if (nslots > 3) ls_row2<NA, COST>(qd_ja[3], qd_jv[3], oc_D[3], al, q);
     } else {
       // hex layout: sub-lane r evaluates row r of every constraint of its leg (limit row r < 3, pyramid row r of the
       // plane contact and of each box slot); the sums below run over all 16 lanes of the env
@@ -1395,10 +1442,10 @@ struct QSolver {
       for (int r = 0; r < 4; r++) jv0[r] = s.con0.row_active ? jx[r] : 0.f;
     }
     float pv[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < (kSubs == 1 ? nslots : (own_any() ? 1 : 0)); k0++) {
-      const int k = kSubs == 1 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
+    for (int k0 = 0; k0 < (kSubs != 4 ? nslots : (own_any() ? 1 : 0)); k0++) {
+      const int k = kSubs != 4 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
       if (!own_on(k)) continue;
-      const QContact cn = kSubs == 1 ? slots.load(k) : mine;
+      const QContact cn = kSubs != 4 ? slots.load(k) : mine;
       float jx[4];
       con_jx(cn, tws, jx);
 #pragma unroll
@@ -1415,6 +1462,24 @@ struct QSolver {
         qd_ja[2 * k] = f2{on ? slots.jar(k, 0) : 0.f, on ? slots.jar(k, 1) : 0.f}; qd_ja[2 * k + 1] = f2{on ? slots.jar(k, 2) : 0.f, on ? slots.jar(k, 3) : 0.f};
         qd_jv[2 * k] = f2{on ? slots.jv(k, 0) : 0.f, on ? slots.jv(k, 1) : 0.f}; qd_jv[2 * k + 1] = f2{on ? slots.jv(k, 2) : 0.f, on ? slots.jv(k, 3) : 0.f};
         qd_D[k] = on ? slots.at(k, 2) : 0.f;
+      }
+    }
+    if (kSubs == 2) {
+      const bool up = (threadIdx.x & 1) != 0;          // sub-lane 1: rows (2, 3)
+      oc_lim_ja = f2{up ? jar_lim[2] : jar_lim[0], up ? 0.f : jar_lim[1]};
+      oc_lim_jv = f2{up ? jv_lim[2] : jv_lim[0], up ? 0.f : jv_lim[1]};
+      oc_lim_D = f2{up ? s.lim_D[2] : s.lim_D[0], up ? 0.f : s.lim_D[1]};
+      oc_pl_ja = f2{up ? jar0[2] : jar0[0], up ? jar0[3] : jar0[1]};
+      oc_pl_jv = f2{up ? jv0[2] : jv0[0], up ? jv0[3] : jv0[1]};
+      if (lds_slots) {
+        const int r0 = up ? 2 : 0;
+#pragma unroll
+        for (int k = 0; k < kMaxB; k++) {
+          const bool on = k < nslots;           // wave-uniform
+          qd_ja[k] = f2{on ? slots.jar(k, r0) : 0.f, on ? slots.jar(k, r0 + 1) : 0.f};
+          qd_jv[k] = f2{on ? slots.jv(k, r0) : 0.f, on ? slots.jv(k, r0 + 1) : 0.f};
+          oc_D[k] = on ? slots.at(k, 2) : 0.f;
+        }
       }
     }
     if (kSubs == 4) {
@@ -1503,12 +1568,12 @@ struct QSolver {
     for (int k = 0; k < 3; k++) { ql[k] += sl[k] * ia; Mal[k] += mvl[k] * ia; jar_lim[k] += jv_lim[k] * ia; }
 #pragma unroll
     for (int r = 0; r < 4; r++) jar0[r] += jv0[r] * ia;
-    for (int k0 = 0; k0 < (kSubs == 1 ? nslots : (own_any() ? 1 : 0)); k0++) {
-      const int k = kSubs == 1 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
+    for (int k0 = 0; k0 < (kSubs != 4 ? nslots : (own_any() ? 1 : 0)); k0++) {
+      const int k = kSubs != 4 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
       if (!own_on(k)) continue;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        if (kSubs == 1) slots.jar(k, r) += slots.jv(k, r) * ia;
+        if (kSubs != 4) slots.jar(k, r) += slots.jv(k, r) * ia;
         else { mjar[r] += mjv[r] * ia; slots.jar(k, r) = mjar[r]; }
       }
     }

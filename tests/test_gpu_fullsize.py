@@ -223,7 +223,7 @@ def test_scan_on_tilted_boxes_matches_the_oracle():
 
 
 def test_configs3_wfc_dr_8192_full_size():
-    """BASELINE configs[3] at its full size: 8192 envs (the batch size at which the launcher switches to the quad lane layout),
+    """BASELINE configs[3] at its full size: 8192 envs (4097..8192 envs run the oct lane layout: 8 envs per wave),
     WFC-generated terrain + full randomize.py DR.  Size-independent properties: bitwise run-to-run determinism, two
     4096-env shards == one batch (DR and RNG streams are keyed by the global env id), finiteness along a rollout with
     AutoReset, scan == analytic box tops of the env's own variant."""
@@ -243,7 +243,7 @@ def test_configs3_wfc_dr_8192_full_size():
         g = np.random.Generator(np.random.Philox(key=[9, k]))
         return torch.from_numpy(np.tanh(g.normal(size=(n, 12)) * 0.6).astype(np.float32)[off:off + cnt]).cuda()
 
-    os.environ["PGTT_LAYOUT"] = "quad"          # the shards must run the layout the full batch selects by itself
+    os.environ["PGTT_LAYOUT"] = "oct"           # the shards must run the layout the full batch selects by itself
     try:
         h0, _ = build(n // 2, 0); h1, _ = build(n // 2, n // 2)
     finally:

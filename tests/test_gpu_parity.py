@@ -195,9 +195,9 @@ def test_flat_parity(layout):
     assert st["active_contacts"] > 1000
 
 
-@pytest.fixture(params=["quad", "hex"])
+@pytest.fixture(params=["quad", "oct", "hex"])
 def layout(request, monkeypatch):
-    """both lane layouts of physics_kernel (pgtt_physics_quad.hip.h): 16 or 4 envs per wave"""
+    """the three lane layouts of physics_kernel (pgtt_physics_quad.hip.h): 16, 8 or 4 envs per wave"""
     monkeypatch.setenv("PGTT_LAYOUT", request.param)
     return request.param
 
@@ -223,7 +223,7 @@ def test_level13_dr_autoreset_parity(layout):
 def test_wfc_terrain_full_dr_parity(layout):
     """BASELINE configs[3] through the parity bar: terrain GENERATED on the host by the wave-function-collapse pipeline
     (terrain_gen.create_random_matrix = terrain/generator.py:368-391 + getIndexes.py:28-79 + wfc) and the full randomize.py DR
-    (go2/randomize.py:23-171), with the AutoReset wrapper on, both lane layouts (8192 envs run the quad layout)"""
+    (go2/randomize.py:23-171), with the AutoReset wrapper on, all lane layouts (8192 envs run the oct layout)"""
     from phase_guided_terrain_traversal_amd.terrain_gen import create_random_matrix
     terrain = create_random_matrix(100, 100, 5, 0.05, 0.13, seed=3)
     assert terrain.shape == (100, 100, 10) and terrain.dtype == np.float32
@@ -246,7 +246,7 @@ def test_ragged_env_counts_parity(layout):
     terrain = np.load(os.path.join(ASSETS, "terrains", "level4.npy"))
     run_parity("stairs", 203, terrain, steps=16)
     run_parity("flat_terrain", 37, None, steps=16)
-    run_parity("flat_terrain", 5, None, steps=8)
+    run_parity("flat_terrain", 5, None, steps=8, w_floor=0.5)        # 40 env-steps: the share of W is 28-33 of them, not a statistic
 
 
 def test_baseline_method_parity():
