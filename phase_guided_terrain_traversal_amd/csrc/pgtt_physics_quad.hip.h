@@ -680,8 +680,8 @@ struct QPhysics {
     mix(m->foot_solref, m->foot_solimp, m->foot_solmix, m->box_solref, m->box_solimp, m->box_solmix, sr, si);
     float margin = fmaxf(m->foot_margin, m->box_margin) - fmaxf(m->foot_gap, m->box_gap);
 #pragma unroll
-    for (int k0 = 0; k0 < (kSubs != 4 ? kMaxB : 1); k0++) {
-      const int k = kSubs != 4 ? k0 : (int)(threadIdx.x & 3);        // hex: sub-lane k completes slot k, in one pass
+    for (int k0 = 0; k0 < (kSubs == 1 ? kMaxB : (kSubs == 2 ? 2 : 1)); k0++) {
+      const int k = kSubs == 1 ? k0 : lane_sub() + kSubs * k0;       // hex: sub-lane k completes slot k, in one pass; oct: slots k, k + 2
       if (__ballot(k < s.nbox) == 0ull) break;
       if (k < s.nbox) {
         QContact cc;
@@ -1063,8 +1063,19 @@ struct QSolver {
   // oct layout: sub-lane 0 evaluates the row pair (0, 1), sub-lane 1 the pair (2, 3) of every constraint of the leg - limit rows
   // (0, 1) / (2, -), the plane contact, box slot k (qd_ja[k] / qd_jv[k] then hold the OWN pair of slot k) - picked once per search
   f2 oc_lim_ja, oc_lim_jv, oc_lim_D, oc_pl_ja, oc_pl_jv; float oc_D[4];
-  PG_INL bool own_on(int k) const { return (k < nslots) | (plane_sub & (k == 3)); }
+  // oct layout: the same idea with two sub-lanes - the units of work of a leg are its box slots 0 .. nslots-1 plus, while a slot is
+  // free (nslots <= 3), the plane contact in slot `plane_slot` = nslots; sub-lane q owns the units q, q + 2 (records and rows stay
+  // in LDS), so the per-contact passes of the Newton loop number ceil(units / 2) instead of units
+  int plane_slot = 3;
+  bool oc_split = false;    // oct layout, wave-uniform: units are shared out between the sub-lanes (two or more box slots in use in the
+                            // wave); otherwise both sub-lanes walk the slots like a lane of the quad layout does (plane contact in
+                            // registers): with a single slot the hand-over through LDS costs more than the second pass it saves
+  PG_INL bool own_on(int k) const { return (k < nslots) | (plane_sub & (k == plane_slot)); }
   PG_INL bool own_any() const { return nslots > 0 || plane_sub; }
+  PG_INL int units() const { return nslots + (plane_sub ? 1 : 0); }
+  // trips of a "for every contact this lane works on" loop and the contact of trip k0
+  PG_INL int own_trips() const { return kSubs == 1 ? nslots : (kSubs == 4 ? (own_any() ? 1 : 0) : (oc_split ? (units() + 1) / 2 : nslots)); }
+  PG_INL int own_slot(int k0) const { return (kSubs == 1 || (kSubs == 2 && !oc_split)) ? k0 : lane_sub() + kSubs * k0; }
   bool any_lim, any_con0;   // wave-uniform: some lane has an active joint-limit row / an active plane contact.
                             // Inactive rows have D = 0 and aref = 0: they add exact zeros, so skipping them is bit-neutral.
   const BoxSlots slots;
@@ -1121,8 +1132,8 @@ struct QSolver {
       for (int r = 0; r < 4; r++) jar0[r] = (s.con0.row_active ? jx[r] : 0.f) - s.con0.aref[r];
     }
     float pv[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < (kSubs != 4 ? nslots : (own_any() ? 1 : 0)); k0++) {
-      const int k = kSubs != 4 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
+    for (int k0 = 0; k0 < own_trips(); k0++) {
+      const int k = own_slot(k0);                                   // hex: every sub-lane works on ITS slot, in one pass; oct: on its one or two
       if (!own_on(k)) continue;
       const QContact cn = kSubs != 4 ? slots.load(k) : mine;
       float jx[4];
@@ -1130,7 +1141,7 @@ struct QSolver {
 #pragma unroll
       for (int r = 0; r < 4; r++) { pv[r] = (cn.row_active ? jx[r] : 0.f) - cn.aref[r]; slots.jar(k, r) = pv[r]; if (kSubs == 4) mjar[r] = pv[r]; }
     }
-    if (plane_sub) {
+    if (kSubs == 4 && plane_sub) {
 #pragma unroll
       for (int r = 0; r < 4; r++) jar0[r] = sub_bcast<3>(pv[r]);
     }
@@ -1164,11 +1175,26 @@ struct QSolver {
       F.l = F.l + fw; F.a = F.a + cross(cn.off, fw);
     };
     if (any_con0 && !plane_sub) add_contact(s.con0, jar0, Fs, csum);
-    if (kSubs != 4) {
+    if (kSubs == 1 || (kSubs == 2 && !oc_split)) {
       for (int k = 0; k < nslots; k++) {
         const QContact cn = slots.load(k);
         float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
         add_contact(cn, ja4, Fs, csum);
+      }
+    } else if (kSubs == 2) {
+      if (own_any()) {
+        // oct layout: each sub-lane forms the force of its own contacts; the sub-lane sum gives both the leg's total
+        S6 Fd{v3(0, 0, 0), v3(0, 0, 0)}; float cd = 0.f;
+        for (int k0 = 0; k0 < own_trips(); k0++) {
+          const int k = own_slot(k0);
+          if (!own_on(k)) continue;
+          const QContact cn = slots.load(k);
+          float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
+          add_contact(cn, ja4, Fd, cd);
+        }
+        Fs.l = Fs.l + v3(sub_sum(Fd.l.x), sub_sum(Fd.l.y), sub_sum(Fd.l.z));
+        Fs.a = Fs.a + v3(sub_sum(Fd.a.x), sub_sum(Fd.a.y), sub_sum(Fd.a.z));
+        csum += sub_sum(cd);
       }
     } else if (own_any()) {
       // hex layout: the owner of a slot forms its force; the sub-lane sum gives every lane the leg's total
@@ -1283,11 +1309,37 @@ struct QSolver {
       }
     };
     if (any_con0 && !plane_sub) add_hessian(s.con0, jar0, Gbb, H.lb, H.ll);
-    if (kSubs != 4) {
+    if (kSubs == 1 || (kSubs == 2 && !oc_split)) {
       for (int k = 0; k < nslots; k++) {
         const QContact cn = slots.load(k);
         float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
         add_hessian(cn, ja4, Gbb, H.lb, H.ll);
+      }
+    } else if (kSubs == 2) {
+      if (own_any()) {
+        // oct layout: the 45 entries of the own contacts (a record that is not in use has finite fields and gets weight 0: exact
+        // zeros), one or two passes, then the sub-lane sums
+        float Gd[21], lbd[18], lld[6];
+        {
+          const int k = lane_sub();
+          QContact cn = slots.load(k);
+          cn.D = own_on(k) ? cn.D : 0.f;
+          float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
+          add_hessian_set(cn, ja4, Gd, lbd, lld);
+        }
+        if (units() > 2) {
+          const int k = lane_sub() + 2;
+          QContact cn = slots.load(k);
+          cn.D = own_on(k) ? cn.D : 0.f;
+          float ja4[4] = {slots.jar(k, 0), slots.jar(k, 1), slots.jar(k, 2), slots.jar(k, 3)};
+          add_hessian(cn, ja4, Gd, lbd, lld);
+        }
+#pragma unroll
+        for (int i = 0; i < 21; i++) Gbb[i] += sub_sum(Gd[i]);
+#pragma unroll
+        for (int i = 0; i < 18; i++) H.lb[i] += sub_sum(lbd[i]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) H.ll[i] += sub_sum(lld[i]);
       }
     } else if (own_any()) {
       // hex layout: the owner of a slot forms its 45 Hessian entries; the sub-lane sums give every lane the leg's total
@@ -1367,11 +1419,12 @@ struct QSolver {
       }
     } else if (kSubs == 2) {
       if (any_lim) ls_row2d<NA, COST>(oc_lim_ja, oc_lim_jv, oc_lim_D, al, q);
-      if (any_con0) ls_row2<NA, COST>(oc_pl_ja, oc_pl_jv, s.con0.D, al, q);
-      if (nslots > 0) ls_row2<NA, COST>(qd_ja[0], qd_jv[0], oc_D[0], al, q);
-      if (nslots > 1) ls_row2<NA, COST>(qd_ja[1], qd_jv[1], oc_D[1], al, q);
-      if (nslots > 2) ls_row2<NA, COST>(qd_ja[2], qd_jv[2], oc_D[2], al, q);
-      if (nslots > 3) ls_row2<NA, COST>(qd_ja[3], qd_jv[3], oc_D[3], al, q);
+      if (any_con0 && !plane_sub) ls_row2<NA, COST>(oc_pl_ja, oc_pl_jv, s.con0.D, al, q);
+      const int nu = units();
+      if (nu > 0) ls_row2<NA, COST>(qd_ja[0], qd_jv[0], oc_D[0], al, q);
+      if (nu > 1) ls_row2<NA, COST>(qd_ja[1], qd_jv[1], oc_D[1], al, q);
+      if (nu > 2) ls_row2<NA, COST>(qd_ja[2], qd_jv[2], oc_D[2], al, q);
+      if (nu > 3) ls_row2<NA, COST>(qd_ja[3], qd_jv[3], oc_D[3], al, q);
     } else {
       // hex layout: sub-lane r evaluates row r of every constraint of its leg (limit row r < 3, pyramid row r of the
       // plane contact and of each box slot); the sums below run over all 16 lanes of the env
@@ -1442,8 +1495,8 @@ struct QSolver {
       for (int r = 0; r < 4; r++) jv0[r] = s.con0.row_active ? jx[r] : 0.f;
     }
     float pv[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < (kSubs != 4 ? nslots : (own_any() ? 1 : 0)); k0++) {
-      const int k = kSubs != 4 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
+    for (int k0 = 0; k0 < own_trips(); k0++) {
+      const int k = own_slot(k0);                                   // hex: every sub-lane works on ITS slot, in one pass; oct: on its one or two
       if (!own_on(k)) continue;
       const QContact cn = kSubs != 4 ? slots.load(k) : mine;
       float jx[4];
@@ -1451,7 +1504,7 @@ struct QSolver {
 #pragma unroll
       for (int r = 0; r < 4; r++) { pv[r] = cn.row_active ? jx[r] : 0.f; slots.jv(k, r) = pv[r]; if (kSubs == 4) mjv[r] = pv[r]; }
     }
-    if (plane_sub) {
+    if (kSubs == 4 && plane_sub) {
 #pragma unroll
       for (int r = 0; r < 4; r++) jv0[r] = sub_bcast<3>(pv[r]);
     }
@@ -1475,7 +1528,7 @@ struct QSolver {
         const int r0 = up ? 2 : 0;
 #pragma unroll
         for (int k = 0; k < kMaxB; k++) {
-          const bool on = k < nslots;           // wave-uniform
+          const bool on = k < units();          // wave-uniform
           qd_ja[k] = f2{on ? slots.jar(k, r0) : 0.f, on ? slots.jar(k, r0 + 1) : 0.f};
           qd_jv[k] = f2{on ? slots.jv(k, r0) : 0.f, on ? slots.jv(k, r0 + 1) : 0.f};
           oc_D[k] = on ? slots.at(k, 2) : 0.f;
@@ -1568,8 +1621,8 @@ struct QSolver {
     for (int k = 0; k < 3; k++) { ql[k] += sl[k] * ia; Mal[k] += mvl[k] * ia; jar_lim[k] += jv_lim[k] * ia; }
 #pragma unroll
     for (int r = 0; r < 4; r++) jar0[r] += jv0[r] * ia;
-    for (int k0 = 0; k0 < (kSubs != 4 ? nslots : (own_any() ? 1 : 0)); k0++) {
-      const int k = kSubs != 4 ? k0 : (int)(threadIdx.x & 3);      // hex: every sub-lane works on ITS slot, in one pass
+    for (int k0 = 0; k0 < own_trips(); k0++) {
+      const int k = own_slot(k0);                                   // hex: every sub-lane works on ITS slot, in one pass; oct: on its one or two
       if (!own_on(k)) continue;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
@@ -1591,6 +1644,14 @@ struct QSolver {
     any_lim = __ballot(s.lim_active[0] || s.lim_active[1] || s.lim_active[2]) != 0ull;
     any_con0 = __ballot(s.con0.row_active) != 0ull;
     plane_sub = kSubs == 4 && lds_slots && nb <= 3 && any_con0;
+    if (kSubs == 2) {
+      // oct layout: with two or three box slots in use somewhere in the wave the plane contact becomes one more unit, in the
+      // first free slot (its record is rewritten every solve; collide() clears the slot's rows before the next one)
+      oc_split = lds_slots && nb >= 2;
+      plane_sub = oc_split && nb <= 3 && any_con0;
+      plane_slot = nb;
+      if (plane_sub) slots.store(nb, s.con0);
+    }
     if (kSubs == 4 && lds_slots) mine = slots.load((int)(threadIdx.x & 3));
     PG_TICK(s, 3);
     // start from the cheaper of (unconstrained acceleration, warm start).  The warm start is evaluated LAST: when it wins

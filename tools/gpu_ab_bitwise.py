@@ -11,7 +11,7 @@ if sys.argv[1] == "--child":
     out, steps = sys.argv[2], int(sys.argv[3])
     res = {}
     for wl in ("level4", "flat"):
-        for lay in ("hex", "quad"):
+        for lay in ("hex", "quad") + (("oct",) if os.environ.get("PGTT_AB_OCT") else ()):
             os.environ["PGTT_LAYOUT"] = lay
             n = 1024
             terrain = None if wl == "flat" else np.load("phase_guided_terrain_traversal_amd/assets/terrains/level4.npy")
