@@ -23,8 +23,6 @@ namespace {
 
 thread_local std::string g_err;
 
-// the oct layout (8 envs per wave) keeps one wave per SIMD up to this batch
-constexpr int kOctMaxEnvs = 8192;
 
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
@@ -122,8 +120,12 @@ void launch_physics(pgtt_env* h, const pgtt::KArgs& a_in, const float* action, h
   // auto: a launch lasts as long as one wave's instruction stream while all its waves run concurrently, one per SIMD (<= 1024
   // waves), and the stream is the shorter the more lanes share an env: hex (4 envs per wave: line-search rows, Cholesky columns
   // and - on box terrain - the collision passes and contact slots split over four sub-lanes) up to 4096 envs (level4 0.18 ms
-  // against 0.39 ms in the quad layout, flat ground 0.137 against 0.141 ms), oct (8 envs per wave) up to 8192, quad beyond
-  const int subs = h->layout != 0 ? h->layout : (h->N <= 4096 ? 4 : (h->N <= kOctMaxEnvs ? 2 : 1));
+  // against 0.39 ms in the quad layout, flat ground 0.137 against 0.141 ms); beyond that oct (8 envs per wave, 34 KB of LDS per
+  // block = four blocks per CU): one round of waves up to 8192 envs, and still ahead of quad (16 envs per wave, 68 KB of LDS =
+  // two blocks per CU) at 16384 and 32768 envs (level4: 27.4 against 23.3 and 29.0 against 25.3 M env-steps/s).  The quad
+  // layout stays available through PGTT_LAYOUT=quad, and is the one for more than 8192 envs on FLAT ground: its flat kernels
+  // use no LDS, 16384 envs are one round of 1024 waves (0.135 ms = 80 M env-steps/s against 51 M in the oct layout's two rounds).
+  const int subs = h->layout != 0 ? h->layout : (h->N <= 4096 ? 4 : ((terr || h->N <= 8192) ? 2 : 1));
   const int per = 16 / subs;
   table[subs == 1 ? 0 : (subs == 4 ? 1 : 2)][MODE][dr ? 1 : 0][terr ? 1 : 0]((h->N + per - 1) / per, st, a, action);
 }

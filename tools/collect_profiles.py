@@ -5,7 +5,9 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, note = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
 for a, b in (("driver_cmd_bench.json", "driver_cmd_bench.json"), ("bench_level4.json", "level4_bench.json"), ("bench_flat.json", "flat_bench.json"), ("bench_wfc_dr_8192.json", "wfc_dr_8192_bench.json"),
-             ("bench_level4_quad.json", "level4_quad_layout_bench.json"), ("kernel_stats.csv", "level4_kernel_stats.csv")):
+             ("bench_level4_quad.json", "level4_quad_layout_bench.json"), ("kernel_stats.csv", "level4_kernel_stats.csv"),
+             ("bench_wfc_dr_8192_quad.json", "wfc_dr_8192_quad_layout_bench.json"), ("bench_level4_8192.json", "level4_8192_bench.json"),
+             ("bench_level4_32768.json", "level4_32768_bench.json"), ("bench_flat_16384.json", "flat_16384_bench.json")):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, f"{tag}_{b}"))
 hdr = (f"# rocprofv3 PMC summary, {tag}: {note}; 4096 envs on level4, per-launch means; collected by tools/profile_round.sh\n"

@@ -7,6 +7,10 @@ python bench.py > $O/bench_level4.json 2>$O/bench_level4.err
 python bench.py --workload flat --no-cpu-baseline > $O/bench_flat.json 2>/dev/null
 python bench.py --workload wfc_dr --envs 8192 --no-cpu-baseline > $O/bench_wfc_dr_8192.json 2>/dev/null
 PGTT_LAYOUT=quad python bench.py --no-cpu-baseline > $O/bench_level4_quad.json 2>/dev/null
+PGTT_LAYOUT=quad python bench.py --workload wfc_dr --envs 8192 --no-cpu-baseline > $O/bench_wfc_dr_8192_quad.json 2>/dev/null
+python bench.py --envs 8192 --no-cpu-baseline > $O/bench_level4_8192.json 2>/dev/null
+python bench.py --envs 32768 --no-cpu-baseline > $O/bench_level4_32768.json 2>/dev/null
+python bench.py --workload flat --envs 16384 --no-cpu-baseline > $O/bench_flat_16384.json 2>/dev/null
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python bench.py --no-cpu-baseline > $O/kt_bench.json 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c -d $O/pmc_$c -o p --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1; done
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU -d $O/pmc_sq -o p --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
