@@ -148,3 +148,33 @@ def test_baseline_task_statistics_against_a_baseline_policy():
         assert rows[name]["mean_dev_sigma"] < 0.25 and 0.88 < rows[name]["std_ratio"] < 1.15, rows[name]
     assert abs(rows["last contact"]["mean_here"] - rows["last contact"]["mean_ref"]) < 0.04
     assert 0.8 < rows["accelerometer"]["std_ratio"] < 1.1 and 0.9 < rows["gravity"]["std_ratio"] < 1.25
+
+
+def test_evaluate_cli_counts_survivors_like_the_reference_evaluator(tmp_path):
+    """evaluate.py (mirror of training/evaluate.py): 1000 evaluation envs with domain randomisation, one episode of 1000 control steps
+    under the deterministic policy, result = number of envs that did not fall.  The reference-trained policies get (nearly) all of them
+    through level4; a checkpoint folder written by the trainer goes through the same entry point."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch
+    import evaluate
+    from phase_guided_terrain_traversal_amd import ppo
+    ns = lambda **kw: evaluate.make_parser().parse_args([]).__class__(**{**vars(evaluate.make_parser().parse_args([])), **kw})
+    r = evaluate.run_evaluation(ns(method="pgtt", terrain_file="level4", policy="policy177"), verbose=False)
+    print(r)
+    assert r["num_eval_envs"] == 1000 and r["survivors"] >= 950 and r["avg_episode_length"] > 950
+    assert r["tracking_lin_vel"] > 0.5                              # share of the maximal tracking reward
+    rb = evaluate.run_evaluation(ns(method="baseline", terrain_file="level4", policy="policy175"), verbose=False)
+    print(rb)
+    assert rb["survivors"] >= 900
+    # an untrained checkpoint through the --checkpoint_folder path: it mostly stands where it is - and earns less than the trained one
+    torch.manual_seed(0)
+    model = ppo.ActorCritic(); dev = "cpu"
+    ck = ppo.checkpoint(model, ppo.RunningNorm(171, dev), ppo.RunningNorm(215, dev))
+    torch.save(ck, tmp_path / "1000.pt")
+    ru = evaluate.run_evaluation(ns(method="pgtt", terrain_file="level4", checkpoint_folder=str(tmp_path)), num_eval_envs=256, verbose=False)
+    print(ru)
+    assert ru["num_eval_envs"] == 256 and ru["episode_reward"] < 0.5 * r["episode_reward"] and ru["tracking_lin_vel"] < r["tracking_lin_vel"]
+    with pytest.raises(SystemExit):
+        evaluate.run_evaluation(ns(method="baseline", terrain_file="level4", policy="policy177"), num_eval_envs=64, verbose=False)
