@@ -1,4 +1,4 @@
-"""Soak: tens of thousands of control steps with random actions, auto-reset and full DR on both layouts; every buffer is checked for
+"""Soak: tens of thousands of control steps with random actions, auto-reset and full DR per lane layout (usage: python tools/gpu_soak.py [layout ...]); every buffer is checked for
 non-finite values and the termination rate is printed."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd())
@@ -7,10 +7,10 @@ from phase_guided_terrain_traversal_amd.env import Joystick
 from phase_guided_terrain_traversal_amd.randomize import domain_randomize
 from phase_guided_terrain_traversal_amd import mjcf
 assets = "phase_guided_terrain_traversal_amd/assets/terrains"
-for lay in ("hex", "quad"):
+for lay in (sys.argv[1:] or ["hex", "quad", "oct"]):
     os.environ["PGTT_LAYOUT"] = lay
     for level, dr in (("level13", True), ("level4", False)):
-        terrain = np.load(f"{assets}/{level}.npy"); n = 4096
+        terrain = np.load(f"{assets}/{level}.npy"); n = 8192 if lay == "oct" else 4096
         kw = {}
         if dr:
             out = domain_randomize(mjcf.load_model("stairs"), n, seed=5, terrain=terrain)
