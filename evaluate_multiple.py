@@ -1,52 +1,49 @@
-"""Mirror of the reference's training/evaluate_multiple.py:9-45: sweep one policy per method over a list of terrain files with
-`evaluate.run_training` and save the per-level counts of evaluation envs (of 1000) that did not fall.
+"""Level sweep of trained policies - what the reference's training/evaluate_multiple.py:9-45 does with `evaluate.run_training`:
+one policy per method, a list of terrain files, per file the number of evaluation envs (of 1000) that get through the episode
+without falling; the two result vectors are saved as plots/pgtt_results.npy and plots/baseline_results.npy.
 
-    python evaluate_multiple.py                                   (the shipped reference-trained policies, shipped levels)
+    python evaluate_multiple.py                                   (the shipped reference-trained policies on the shipped levels)
     python evaluate_multiple.py --pgtt checks_stairs/checkpoint_122 --baseline checks_stairs/checkpoint_125 --levels terrains/level09.npy ...
 
-The reference sweeps `terrains/level09.npy .. level11.npy` (generated by terrain/generator.py:430-437, not in its repository) with
-checkpoints 122 (pgtt) and 125 (baseline); the defaults here are what ships: levels 4, 7, 10, 13 and the exported policy177 / policy175.
-A policy argument is a checkpoint folder of train.py, an .npz path, or the name of a shipped policy.
+The reference sweeps `terrains/level09.npy .. level11.npy` (files its terrain/generator.py:430-437 writes; they are not in its
+repository) with its checkpoints 122 (pgtt) and 125 (baseline).  The defaults here are what ships: levels 4, 7, 10, 13 and the
+exported policy177 / policy175.  A policy argument is a checkpoint folder of train.py, an .npz path, or a shipped policy's name.
 """
 import argparse
 import os
-from types import SimpleNamespace
 
 import numpy as np
 
-from evaluate import run_training
+import evaluate
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
-
-
-def sweep(method, policy, levels):
-    results = []
-    for terrain in levels:
-        is_dir = os.path.isdir(policy)
-        args = SimpleNamespace(method=method, checkpoint_folder=policy if is_dir else None, policy=None if is_dir else policy, task_name="stairs",
-                               terrain_file=terrain, num_envs=4096, batch_size=256, discount=0.97, learning_rate=3e-4, num_minibatches=32,
-                               num_timesteps=1, num_evals=31, index=0)
-        print(f"-> [{method}] running on {terrain} ...", flush=True)
-        r = run_training(args)
-        print(f"   {r} of 1000")
-        results.append(r)
-    return results
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--pgtt", default="policy177")
-    ap.add_argument("--baseline", default="policy175")
-    ap.add_argument("--levels", nargs="*", default=["level4", "level7", "level10", "level13"])
-    a = ap.parse_args()
-    pgtt_results = sweep("pgtt", a.pgtt, a.levels)
-    base_results = sweep("baseline", a.baseline, a.levels)
-    os.makedirs(os.path.join(ROOT, "plots"), exist_ok=True)
-    np.save(os.path.join(ROOT, "plots", "pgtt_results.npy"), np.array(pgtt_results))
-    np.save(os.path.join(ROOT, "plots", "baseline_results.npy"), np.array(base_results))
-    print("\nlevels  ", a.levels, "\npgtt    ", pgtt_results, "\nbaseline", base_results)
-    print("Saved: plots/pgtt_results.npy, plots/baseline_results.npy")
+def survivors_per_level(method, policy, levels):
+    """[number of the 1000 evaluation envs that did not fall, for every terrain file]"""
+    source = ["--checkpoint_folder", policy] if os.path.isdir(policy) else ["--policy", policy]
+    counts = []
+    for level in levels:
+        args = evaluate.make_parser().parse_args(["--method", method, "--task_name", "stairs", "--terrain_file", level] + source)
+        res = evaluate.run_evaluation(args, verbose=False)
+        print(f"[{method:8s}] {level:>24s}: {res['survivors']:4d} of {res['num_eval_envs']}   reward / episode {res['episode_reward']:7.2f}   "
+              f"tracking lin {res['tracking_lin_vel']:.2f} ang {res['tracking_ang_vel']:.2f}", flush=True)
+        counts.append(res["survivors"])
+    return counts
 
 
 if __name__ == "__main__":
-    main()
+    ap = argparse.ArgumentParser(description="sweep a pgtt and a baseline policy over terrain levels")
+    ap.add_argument("--pgtt", default="policy177")
+    ap.add_argument("--baseline", default="policy175")
+    ap.add_argument("--levels", nargs="*", default=["level4", "level7", "level10", "level13"])
+    opt = ap.parse_args()
+    table = {"pgtt": survivors_per_level("pgtt", opt.pgtt, opt.levels), "baseline": survivors_per_level("baseline", opt.baseline, opt.levels)}
+    out = os.path.join(HERE, "plots")
+    os.makedirs(out, exist_ok=True)
+    for name, counts in table.items():
+        np.save(os.path.join(out, f"{name}_results.npy"), np.array(counts))
+    print("\nlevels  ", opt.levels)
+    for name, counts in table.items():
+        print(f"{name:8s}", counts)
+    print(f"saved: {out}/pgtt_results.npy, {out}/baseline_results.npy")
