@@ -17,8 +17,11 @@ over the action pool with the kernel events recorded on every step, two interval
 nothing in the timed window loads a code object or creates an event for the first time.  `wall_over_kernels` =
 ms_per_step / (physics + observe + the interval reduction's share of a step); "cold": true (and exit code 3) when it exceeds 1.5.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (physics_kernel); `cpu_baseline` is the
-build's own CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded sample.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (physics_kernel) with ITS share of the algorithmic work
+(1.2 MFLOP, 0.8 KB per env-step), `roofline_observe` / `roofline_step` the scan kernel and the whole step; `cpu_baseline` is the
+build's own CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded sample.  With one GPU the line
+also carries `other_configs`: BASELINE configs[1] (flat, 4096), configs[3] (WFC + DR, 8192) and level4 at 32768 envs, 20 steps
+each after the headline window (never part of `value`; --no-other-configs skips them).
 
 `--backend gloo` is a TEST HOOK (tests/test_distributed.py): CPU tensors and a stub env, so that the rank / barrier /
 MAX-over-ranks / rank-0-print path of this file runs without a GPU; its line carries "stub": true and is not a result.
@@ -36,10 +39,16 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic per-env-step figures (restated in DESIGN.md)
+# algorithmic per-env-step figures (restated in DESIGN.md 6): the whole control step, and its split over the two kernels
 ALGO_BYTES_PER_ENV_STEP = 3456          # no-DR workload; 4216 with per-env DR params
 ALGO_BYTES_PER_ENV_STEP_DR = 4216
-ALGO_FLOP_PER_ENV_STEP = 1.6e6          # fp32, dense MJX formulation (the reference's arithmetic)
+ALGO_FLOP_PER_ENV_STEP = 1.6e6          # fp32, dense MJX formulation (the reference's arithmetic): 4 x 0.30 physics + 0.35 scan + task layer
+ALGO_FLOP_PHYSICS = 1.2e6               # 4 substeps x 0.30 MFLOP (kinematics, CRBA, factor, RNE, collision, 44-row constraint build, Newton x line search)
+ALGO_FLOP_OBSERVE = 0.35e6              # 117 rays x 101 geoms x ~30 (+ < 0.01 MFLOP of task layer)
+# physics_kernel's own compulsory rows: reads qpos 19 + qvel 18 + warm start 18 + action 12 = 67, writes qpos 19 + qvel 18 + warm start 18
+# + motor targets 12 + sensor frame 65 = 132 floats -> 796 B per env-step (+ 77 DR rows = 308 B and one box-friction row per contact with DR)
+ALGO_BYTES_PHYSICS = 4 * (67 + 132)
+ALGO_BYTES_PHYSICS_DR = ALGO_BYTES_PHYSICS + 4 * 77
 PEAK_FP32_TFLOPS = 157.3                # MI355X fp32 vector peak (MI355X_MICROARCH.md); the fp32 matrix peak is the same number
 PEAK_HBM_GBS = 8000.0
 CURRICULUM = [1, 2, 3, 4, 7, 10, 13]    # the level files the reference ships (terrains/level*.npy), easiest first
@@ -58,6 +67,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-steps", type=int, default=100)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU test hook with a stub env (not a result)")
+    ap.add_argument("--layout", default="auto", choices=["auto", "quad", "oct", "hex"], help="lane layout of physics_kernel (PgttConfig.lane_layout)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other single-GPU configs after the headline window")
+    ap.add_argument("--other-steps", type=int, default=20)
     return ap.parse_args(argv)
 
 
@@ -106,7 +118,7 @@ def build_env(args, rank, world, local):
     n = args.envs
     off = rank * n
     assets = os.path.join(ROOT, "phase_guided_terrain_traversal_amd", "assets", "terrains")
-    cfg = configs.training_config()
+    cfg = dict(configs.training_config(), lane_layout=args.layout)
     kw, terrain, task, dr = {}, None, "stairs", False
     if args.workload == "flat":
         task = "flat_terrain"
@@ -126,39 +138,31 @@ def build_env(args, rank, world, local):
         out = domain_randomize(mjcf.load_model("stairs"), n, seed=3, terrain=terrain, env_id_offset=off)
         kw = {"variant": torch.from_numpy(out["variant"]), "params": torch.from_numpy(out["params"]),
               "box_friction": torch.from_numpy(out["box_friction"])}
-    env = Joystick(task, cfg, num_envs=n, terrain=terrain, device=f"cuda:{local}", autoreset=True, env_id_offset=off, **kw)
+    env = Joystick(task, cfg, num_envs=n, terrain=terrain, device=f"cuda:{local}", autoreset=True, env_id_offset=off, interval_sums=True, **kw)
     return env, cfg, terrain, task, dr
 
 
-def worker(args):
+WORKLOAD_TEXT = {
+    "level4": "4096 Go2 envs/GPU, terrains/level4.npy (100 variants x 100 boxes) + 13x9 height scan, no DR (BASELINE configs[2])",
+    "flat": "4096 Go2 envs/GPU, plane only, no DR (BASELINE configs[1])",
+    "level13_dr": "Go2 envs/GPU, level13 + full randomize.py DR (BASELINE configs[3] shape)",
+    "curriculum": "Go2 envs/GPU, rank r on stage r of terrains/level{1,2,3,4,7,10,13}.npy + height scan, no DR (BASELINE configs[4])",
+    "wfc_dr": "Go2 envs/GPU, WFC-generated stairs (terrain_gen.py, 100 variants) + full randomize.py DR (BASELINE configs[3])"}
+# the other single-GPU configurations of BASELINE.json, timed for a few steps after the headline window (world == 1 only)
+OTHER_CONFIGS = [("flat", 4096, "BASELINE configs[1]"), ("wfc_dr", 8192, "BASELINE configs[3]"), ("level4", 32768, "single-GPU saturation of configs[2]")]
+
+
+def timed_window(env, n, steps, warmup, dev, rank, world, stub, sync):
+    """prime every code path, W untimed warm-up steps, then EXACTLY `steps` steps between barrier + synchronize on both sides.
+    -> dict(dt = max-over-ranks wall seconds, ranks, physics_ms, observe_ms, launches, gemv_ms, env_steps)"""
     import torch
     import torch.distributed as dist
-    from phase_guided_terrain_traversal_amd.distributed import MetricReducer, init_from_env
-
-    stub = args.backend == "gloo"
-    rank, local, world = init_from_env(args.backend)
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus} "
-                         f"(or run `python bench.py --gpus {args.gpus}` without a torchrun environment: it spawns the ranks)")
-    if stub:
-        dev = torch.device("cpu")
-        env, cfg, terrain, task, dr = StubEnv(args.envs, rank), None, None, "stub", False
-        sync = lambda: None
-    else:
-        if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
-            raise SystemExit(f"rank {rank}: no GPU {local} (device_count = {torch.cuda.device_count() if torch.cuda.is_available() else 0}); "
-                             "the bench has no CPU path")
-        torch.cuda.set_device(local)
-        dev = torch.device("cuda", local)
-        env, cfg, terrain, task, dr = build_env(args, rank, world, local)
-        sync = torch.cuda.synchronize
-    n = args.envs
+    from phase_guided_terrain_traversal_amd.distributed import MetricReducer
     env.reset(seed=0)
     g = torch.Generator(device=dev); g.manual_seed(1 + rank)
     pool = [torch.tanh(torch.randn(n, 12, generator=g, device=dev) * 0.6) for _ in range(32)]   # tanh(N(0,0.6)), SURVEY 8d
     reducer = MetricReducer(dev)
     env_steps_seen = torch.zeros((), dtype=torch.float64, device=dev)     # sum of the all-reduced env-step counts
-
     sums = env.buffers["interval_sums"]          # [22 metrics; reward; done][N] running sums kept by the step kernels
 
     def flush(nsteps):
@@ -186,7 +190,7 @@ def worker(args):
     sums.zero_(); reducer.reduce(); env_steps_seen.zero_()               # counters back to zero
     # ---- the W untimed warm-up steps of the contract
     env.enable_timing(8)          # every 8th step: an event record costs a few us of GPU idle
-    run(0, args.warmup)
+    run(0, warmup)
     sync()
     sums.zero_(); reducer.reduce()
     env_steps_seen.zero_()
@@ -195,15 +199,15 @@ def worker(args):
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    run(0, args.steps)
+    run(0, steps)
     sync()
     if world > 1:
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
     ranks = 1
-    if args.steps % REDUCE_EVERY:
-        flush(args.steps % REDUCE_EVERY)                    # the tail of the last interval (outside the clock)
+    if steps % REDUCE_EVERY:
+        flush(steps % REDUCE_EVERY)                    # the tail of the last interval (outside the clock)
     if world > 1:
         t = torch.tensor([dt, 1.0], device=dev, dtype=torch.float64)
         tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -211,57 +215,132 @@ def worker(args):
         dt, ranks = float(tm[0].item()), int(round(float(ts[1].item())))
     phys_ms, obs_ms, ntimed = env.kernel_ms_mean()
     env.enable_timing(False)
-    done_frac = float(env.buffers["done"].mean().item())
-    env_steps = float(env_steps_seen.item())
+    return {"dt": dt, "ranks": ranks, "physics_ms": phys_ms, "observe_ms": obs_ms, "launches": ntimed, "gemv_ms": gemv_ms,
+            "env_steps": float(env_steps_seen.item()), "done_frac": float(env.buffers["done"].mean().item())}
+
+
+def profile_record(workload, n):
+    """counter figures measured with rocprofv3 --pmc on the same command and committed under profiles/ (hbm_traffic.json,
+    tools/collect_profiles.py): HBM bytes per physics_kernel launch, VALU-busy share of the wave cycles.  None when not measured."""
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        return json.load(open(tpath)).get(f"{workload}_{n}", {})
+    except Exception:
+        return {}
+
+
+def rooflines(w, workload, n, dr, ms_per_step):
+    """`roofline` (dominant kernel = physics_kernel, its OWN share of the algorithmic work), `roofline_observe`, `roofline_step`
+    (whole step over the wall time per step) and `roofline_hbm`.  Flops are the dense-MJX count of SURVEY 8d - the arithmetic of the
+    reference, not what this formulation executes (arrowhead M / H: about a quarter) - so `valu_busy` from the counters is the
+    better reading of how busy the machine is."""
+    rec = profile_record(workload, n)
+    traffic = rec.get("physics_bytes_per_launch")
+    pf, of = ALGO_FLOP_PHYSICS * n, ALGO_FLOP_OBSERVE * n
+    pb = (ALGO_BYTES_PHYSICS_DR if dr else ALGO_BYTES_PHYSICS) * n
+    sb = (ALGO_BYTES_PER_ENV_STEP_DR if dr else ALGO_BYTES_PER_ENV_STEP) * n
+
+    def line(bound, work, ms, peak, unit, scale, **extra):
+        a = work / (ms * 1e-3) / scale
+        return dict({"bound": bound, "achieved": a, "peak": peak, "unit": unit, "frac": a / peak}, **extra)
+    return {
+        "roofline": line("valu_fp32", pf, w["physics_ms"], PEAK_FP32_TFLOPS, "TFLOP/s", 1e12, traffic=traffic, kernel="physics_kernel",
+                         algorithmic_flop_per_env_step=ALGO_FLOP_PHYSICS, algorithmic_bytes_per_launch=pb,
+                         traffic_over_algorithmic=(traffic / pb if traffic else None), valu_busy=rec.get("valu_busy"), mfma_ops=rec.get("mfma_ops"),
+                         note="FP32 vector-ALU issue / latency bound (SURVEY 8d): physics share of the dense-MJX count, 4 x 0.30 MFLOP per env-step; "
+                              "MFMA deliberately unused (DESIGN 5.1); valu_busy = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES from profiles/"),
+        "roofline_observe": line("valu_fp32", of, w["observe_ms"], PEAK_FP32_TFLOPS, "TFLOP/s", 1e12, kernel="observe_kernel",
+                                 algorithmic_flop_per_env_step=ALGO_FLOP_OBSERVE),
+        "roofline_step": line("valu_fp32", ALGO_FLOP_PER_ENV_STEP * n, ms_per_step, PEAK_FP32_TFLOPS, "TFLOP/s", 1e12,
+                              algorithmic_flop_per_env_step=ALGO_FLOP_PER_ENV_STEP, over="ms_per_step (wall)"),
+        "roofline_hbm": line("hbm", pb, w["physics_ms"], PEAK_HBM_GBS, "GB/s", 1e9, traffic=traffic, kernel="physics_kernel",
+                             step_algorithmic_bytes_per_launch=sb, step_GBps=sb / (ms_per_step * 1e-3) / 1e9),
+    }
+
+
+def other_configs(args, local, dev, sync):
+    """configs[1], configs[3] and the single-GPU saturation point, a few steps each (same priming + barrier discipline as the
+    headline; builder-side series with 200+ steps live under profiles/).  Never part of `value`."""
+    import copy
+    rows = []
+    for workload, n, what in OTHER_CONFIGS:
+        a2 = copy.copy(args); a2.workload, a2.envs = workload, n
+        t0 = time.perf_counter()
+        env, cfg, terrain, task, dr = build_env(a2, 0, 1, local)
+        w = timed_window(env, n, args.other_steps, 5, dev, 0, 1, False, sync)
+        env.close()
+        ms = 1e3 * w["dt"] / args.other_steps
+        r = rooflines(w, workload, n, dr, ms)
+        rows.append({"workload": workload, "envs": n, "what": what, "value": w["env_steps"] / w["dt"], "unit": "env-steps/s", "steps": args.other_steps,
+                     "ms_per_step": ms, "kernels_ms": {"physics_kernel": w["physics_ms"], "observe_kernel": w["observe_ms"]},
+                     "wall_over_kernels": ms / (w["physics_ms"] + w["observe_ms"] + w["gemv_ms"]),
+                     "roofline_frac_physics": r["roofline"]["frac"], "traffic": r["roofline"]["traffic"], "lane_layout": args.layout,
+                     "setup_s": time.perf_counter() - t0 - w["dt"]})
+    return rows
+
+
+def worker(args):
+    import torch
+    import torch.distributed as dist
+    from phase_guided_terrain_traversal_amd.distributed import MetricReducer, init_from_env
+
+    stub = args.backend == "gloo"
+    rank, local, world = init_from_env(args.backend)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}` without a torchrun environment: it spawns the ranks)")
+    if stub:
+        dev = torch.device("cpu")
+        env, cfg, terrain, task, dr = StubEnv(args.envs, rank), None, None, "stub", False
+        sync = lambda: None
+    else:
+        if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
+            raise SystemExit(f"rank {rank}: no GPU {local} (device_count = {torch.cuda.device_count() if torch.cuda.is_available() else 0}); "
+                             "the bench has no CPU path")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        env, cfg, terrain, task, dr = build_env(args, rank, world, local)
+        sync = torch.cuda.synchronize
+    n = args.envs
+    w = timed_window(env, n, args.steps, args.warmup, dev, rank, world, stub, sync)
+    dt, ranks, env_steps = w["dt"], w["ranks"], w["env_steps"]
+    env.close()
 
     rc = 0
     if rank == 0:
         value = env_steps / dt               # env-steps the all-reduce counted over ALL ranks / max-over-ranks wall time
-        kern = phys_ms + obs_ms + gemv_ms
-        ratio = 1e3 * dt / args.steps / kern
-        algo_bytes = (ALGO_BYTES_PER_ENV_STEP_DR if dr else ALGO_BYTES_PER_ENV_STEP) * n
-        algo_flop = ALGO_FLOP_PER_ENV_STEP * n
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f"{args.workload}_{n}", {}).get("physics_bytes_per_launch")
-            except Exception:
-                traffic = None
+        ms_per_step = 1e3 * dt / args.steps
+        kern = w["physics_ms"] + w["observe_ms"] + w["gemv_ms"]
+        ratio = ms_per_step / kern
         out = {
             "metric": "env-steps/sec at 4096 envs (Go2, level4 hfield), 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": ranks, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"level4": "4096 Go2 envs/GPU, terrains/level4.npy (100 variants x 100 boxes) + 13x9 height scan, no DR (BASELINE configs[2])",
-                                    "flat": "4096 Go2 envs/GPU, plane only, no DR (BASELINE configs[1])",
-                                    "level13_dr": "Go2 envs/GPU, level13 + full randomize.py DR (BASELINE configs[3] shape)",
-                                    "curriculum": "Go2 envs/GPU, rank r on stage r of terrains/level{1,2,3,4,7,10,13}.npy + height scan, no DR (BASELINE configs[4])",
-                                    "wfc_dr": "Go2 envs/GPU, WFC-generated stairs (terrain_gen.py, 100 variants) + full randomize.py DR (BASELINE configs[3])"}[args.workload],
+            "config": {"workload": WORKLOAD_TEXT[args.workload],
                        "envs_per_gpu": n, "substeps": 4, "autoreset": True, "actions": "tanh(N(0,0.6)) iid", "parallelism": f"env-shard x{world}",
+                       "lane_layout": args.layout,
                        "collective": f"fused {MetricReducer.SIZE}-float all-reduce every {REDUCE_EVERY} steps ({args.backend})"},
             "env_steps_allreduced": env_steps, "env_steps_expected": float(n) * world * args.steps,
-            "kernels_ms": {"physics_kernel": phys_ms, "observe_kernel": obs_ms, "interval_reduce_per_step": gemv_ms, "launches": ntimed},
+            "kernels_ms": {"physics_kernel": w["physics_ms"], "observe_kernel": w["observe_ms"], "interval_reduce_per_step": w["gemv_ms"], "launches": w["launches"]},
             "wall_over_kernels": ratio, "cold": bool(ratio > COLD_RATIO),
-            "done_fraction_last_step": done_frac,
-            "roofline": {"bound": "valu_fp32", "achieved": algo_flop / (phys_ms * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": algo_flop / (phys_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "kernel": "physics_kernel", "note": "FP32 vector-ALU issue / latency bound (SURVEY 8d); algorithmic flops = dense-MJX count 1.6 MFLOP per env-step"},
-            "roofline_hbm": {"bound": "hbm", "achieved": algo_bytes / (phys_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": algo_bytes / (phys_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": traffic},
+            "done_fraction_last_step": w["done_frac"],
         }
         if stub:
             out.update(stub=True, roofline=None, roofline_hbm=None, kernels_ms=None)
+        else:
+            out.update(rooflines(w, args.workload, n, dr, ms_per_step))
         if env_steps != float(n) * world * args.steps or ranks != world:
             out["error"] = f"all-reduce saw {env_steps} env-steps from {ranks} ranks, expected {float(n) * world * args.steps} from {world}"
             rc = 4
+        if world == 1 and not stub and not args.no_other_configs:
+            out["other_configs"] = other_configs(args, local, dev, sync)
         if world == 1 and not args.no_cpu_baseline and not stub:
             out["cpu_baseline"] = cpu_baseline(args, cfg, terrain, task, n)
         print(json.dumps(out), flush=True)
         if out["cold"] and not stub:
             print(f"bench.py: wall time is {ratio:.2f} x the kernel time: the timed window is not kernel-bound (cold code or host-bound launch loop)", file=sys.stderr)
             rc = rc or 3
-    env.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -58,7 +58,7 @@ def run_evaluation(args, num_eval_envs=NUM_EVAL_ENVS, seed=0, verbose=True):
     """-> dict(survivors, num_eval_envs, episode_reward, avg_episode_length, tracking_lin_vel, tracking_ang_vel)"""
     if args.method not in ("pgtt", "baseline"):
         raise SystemExit("--method must be pgtt (go2/joystick_pgtt.py) or baseline (go2/joystick.py)")
-    cfg = configs.training_config(args.method)
+    cfg = configs.evaluation_config(args.method)          # training/evaluate.py:127-129: commands within +-[0.4, 0.4, 0.7]
     model = mjcf.load_model(args.task_name)
     terrain = load_terrain(args.terrain_file) if args.task_name == "stairs" else None
     n = num_eval_envs

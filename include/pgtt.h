@@ -141,7 +141,15 @@ typedef struct PgttConfig {
   float scan_z_offset;            /* 0.6 (heightmap.py:38) */
   int32_t autoreset;              /* 1: fuse Episode(1000)+AutoReset-to-first-state wrapper semantics into step */
   int32_t method;                 /* PGTT_METHOD_*: observation layout, H_max definition, clearance target, air-time threshold */
+  /* execution options (no counterpart in the reference; they choose between kernels that compute the same step) */
+  int32_t lane_layout;            /* PGTT_LAYOUT_*: lanes per env of physics_kernel.  AUTO goes by the per-GPU batch; results are bit-identical
+                                   * between batch sizes / shards only WITHIN one layout (between layouts: fp32 rounding), so a job that must
+                                   * reproduce another one's bits pins the layout here */
+  int32_t observe_form;           /* PGTT_OBSERVE_*: scan + obs + rewards as one kernel or as observe + task kernels */
+  int32_t test_hooks;             /* non-zero: pgtt_set_test_overrides is allowed on this handle (fixture replay); 0 in production */
 } PgttConfig;
+enum { PGTT_LAYOUT_AUTO = 0, PGTT_LAYOUT_QUAD = 1, PGTT_LAYOUT_OCT = 2, PGTT_LAYOUT_HEX = 4 };   /* 4, 8, 16 lanes per env */
+enum { PGTT_OBSERVE_FUSED = 0, PGTT_OBSERVE_SPLIT = 1 };
 
 /* ---------------------------------------------------------------- persistent per-env state rows (float SoA) */
 enum {
@@ -258,7 +266,7 @@ int pgtt_physics(pgtt_handle h, const float* action_Nx12, void* stream);  /* 4 x
 int pgtt_observe(pgtt_handle h, const float* action_Nx12, void* stream);  /* scan + obs + rewards + bookkeeping */
 int pgtt_scan(pgtt_handle h, float yaw_override_or_nan, void* stream);     /* K11 alone -> scan_z */
 
-/* TEST HOOKS (off by default; tests/test_gpu_golden.py): the reference-generated fixtures of Joystick.step / Joystick.reset
+/* TEST HOOKS (refused with PGTT_E_STATE unless the handle was created with PgttConfig.test_hooks != 0; tests/test_gpu_golden.py): the reference-generated fixtures of Joystick.step / Joystick.reset
  * (go2/joystick_pgtt.py:50-131,141-231 executed with jax.random stubbed and fake physics outputs) can only be replayed when every
  * uniform draw returns a fixed value (rng_value; NaN = the Philox streams) and when the step takes the 117 scan heights from
  * buf.scan_z instead of casting rays (scan_preset != 0). */
@@ -278,20 +286,6 @@ int pgtt_obs_dims(const PgttConfig* cfg, int* state_dim, int* priv_dim);
 int pgtt_sizeof_model(void);
 int pgtt_sizeof_config(void);
 int pgtt_sizeof_buffers(void);
-/* Trainer-side helper (not part of the env step; replaces no reference entry point - the reference's PPO is Brax's):
- * the policy part of the PPO minibatch loss, -mean(min(r a, clip(r) a)) - entropy_cost * mean(entropy), of a tanh-normal
- * policy head (loc | raw scale, scale = softplus(raw) + 1e-3; the Brax loss configured at training/train.py:135-161) and its
- * gradient with respect to the network output, in one launch + a single-wave finish instead of ~100 elementwise launches.
- * All pointers are device pointers (float32); partial holds 2 * ceil(B / 64) floats of scratch; loss_3 = {total, policy
- * term, mean entropy}; A must be 12.  Enqueued on `stream`, no synchronisation. */
-int pgtt_ppo_policy_loss(const float* out_Bx2A, const float* u_BxA, const float* logp_old_B, const float* adv_B,
-                         const float* eps_BxA, int B, int A, float clip_eps, float entropy_cost,
-                         float* partial_2xceilB64, float* loss_3, float* grad_Bx2A, void* stream);
-/* Trainer-side helper: weight and bias gradient of a Linear layer over a long batch, dW[n][m] = sum_k dY[k][n] X[k][m],
- * db[n] = sum_k dY[k][n] (X [K][M], dY [K][N], dW in torch's [N][M] layout), K split over S workgroups per 64x64 tile on
- * fp32 MFMA, summed in a fixed order.  partial holds S * (N * M + N) floats of scratch.  Device pointers, caller's stream. */
-int pgtt_ppo_linear_backward(const float* x_KxM, const float* dy_KxN, int K, int M, int N, int S,
-                             float* partial_Sx_NM_plus_N, float* dw_NxM, float* db_N, void* stream);
 const char* pgtt_version(void);
 const char* pgtt_last_error(void);
 

@@ -37,7 +37,8 @@ def use_fast_build() -> str:
 
 def lib() -> C.CDLL:
     if _LIB is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        # PGTT_ORACLE_LIB: another build of the same checker (oracle/Makefile: `make san` ASan + UBSan, `make flip`)
+        path = os.environ.get("PGTT_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(path):
             build()
         _load(path)

@@ -16,6 +16,8 @@ SCAN_H, SCAN_W, NSCAN = 13, 9, 117
 OBS, PRIV, NREW, NMETRIC = 171, 215, 21, 22
 OBS_BASELINE, PRIV_BASELINE = 162, 206          # go2/joystick.py: no phase (8) / gait_freq (1) rows
 METHODS = {"pgtt": 0, "baseline": 1}
+LAYOUTS = {"auto": 0, "quad": 1, "oct": 2, "hex": 4}        # PGTT_LAYOUT_*: 4 / 8 / 16 lanes per env in physics_kernel
+OBSERVE_FORMS = {"fused": 0, "split": 1}                    # PGTT_OBSERVE_*
 
 
 def obs_dims(method="pgtt"):
@@ -73,7 +75,7 @@ class PgttConfig(C.Structure):
         ("reward_scale", f * NREW), ("tracking_sigma", f), ("swing_height", f), ("base_feet_distance", f),
         ("phase_sigma", f), ("cmd_u_max", f * 3), ("cmd_u_min", f * 3), ("cmd_b", f * 3),
         ("gait_freq", f * 2), ("scan_dist_x", f), ("scan_dist_y", f), ("scan_z_offset", f),
-        ("autoreset", i32), ("method", i32),
+        ("autoreset", i32), ("method", i32), ("lane_layout", i32), ("observe_form", i32), ("test_hooks", i32),
     ]
 
 
@@ -151,4 +153,7 @@ def config_struct(cfg: Dict[str, Any]) -> PgttConfig:
     s.scan_dist_x, s.scan_dist_y, s.scan_z_offset = cfg["scan_dist_x"], cfg["scan_dist_y"], cfg["scan_z_offset"]
     s.autoreset = int(cfg.get("autoreset", 0))
     s.method = METHODS[cfg.get("method", "pgtt")]
+    s.lane_layout = LAYOUTS[cfg.get("lane_layout", "auto")]
+    s.observe_form = OBSERVE_FORMS[cfg.get("observe_form", "fused")]
+    s.test_hooks = int(bool(cfg.get("test_hooks", False)))
     return s

@@ -56,6 +56,16 @@ def training_config(method: str = "pgtt") -> Dict[str, Any]:
     return cfg
 
 
+def evaluation_config(method: str = "pgtt") -> Dict[str, Any]:
+    """the evaluator's env of training/evaluate.py:120-129: default_config() / baseline_config() with the NARROWER command range
+    u_max = [0.4, 0.4, 0.7], u_min = -u_max and gait_freq = [1, 3] (survivor counts are quoted on these commands, not on training's +-0.6 / 1.0)."""
+    cfg = default_config() if method == "pgtt" else baseline_config()
+    cfg["command_config"]["u_max"] = [0.4, 0.4, 0.7]
+    cfg["command_config"]["u_min"] = [-0.4, -0.4, -0.7]
+    cfg["gait_freq"] = [1, 3]
+    return cfg
+
+
 def with_overrides(cfg: Dict[str, Any], **kw) -> Dict[str, Any]:
     out = copy.deepcopy(cfg)
     for k, v in kw.items():

@@ -51,8 +51,8 @@ struct pgtt_env {
   float test_rng_fix = NAN; int test_scan_preset = 0;   // pgtt_set_test_overrides
   bool timing = false;
   int timing_period = 1, timing_tick = 0; bool timing_now = false;   // time every timing_period-th step (event records cost ~3 us of GPU idle each)
-  bool split_observe = false;     // observe = observe_kernel<OBS_STEP_OBS> + task_kernel (PGTT_OBSERVE=split|fused forces)
-  int layout = 0;                 // lane layout of physics_kernel: 1 quad (16 envs per wave), 4 hex (4 envs per wave), 0 auto
+  bool split_observe = false;     // observe = observe_kernel<OBS_STEP_OBS> + task_kernel (PgttConfig.observe_form)
+  int layout = 0;                 // lane layout of physics_kernel (PGTT_LAYOUT_*): 1 quad (16 envs per wave), 2 oct (8), 4 hex (4), 0 auto
   // kernel timing: a ring of event quadruples (physics begin / end, observe begin / end), one per step; a slot is
   // read back when it comes up for re-use (its step finished long ago: no stall) or by pgtt_kernel_ms_mean()
   static constexpr int kRing = 64;
@@ -123,7 +123,7 @@ void launch_physics(pgtt_env* h, const pgtt::KArgs& a_in, const float* action, h
   // against 0.39 ms in the quad layout, flat ground 0.137 against 0.141 ms); beyond that oct (8 envs per wave, 34 KB of LDS per
   // block = four blocks per CU): one round of waves up to 8192 envs, and still ahead of quad (16 envs per wave, 68 KB of LDS =
   // two blocks per CU) at 16384 and 32768 envs (level4: 27.4 against 23.3 and 29.0 against 25.3 M env-steps/s).  The quad
-  // layout stays available through PGTT_LAYOUT=quad, and is the one for more than 8192 envs on FLAT ground: its flat kernels
+  // layout stays available through PgttConfig.lane_layout, and is the one for more than 8192 envs on FLAT ground: its flat kernels
   // use no LDS, 16384 envs are one round of 1024 waves (0.135 ms = 80 M env-steps/s against 51 M in the oct layout's two rounds).
   const int subs = h->layout != 0 ? h->layout : (h->N <= 4096 ? 4 : ((terr || h->N <= 8192) ? 2 : 1));
   const int per = 16 / subs;
@@ -166,6 +166,9 @@ int pgtt_create(const PgttConfig* cfg, const PgttModel* model, int device, int n
   if (num_envs <= 0) return fail(PGTT_E_ARG, "pgtt_create: num_envs must be positive");
   if (cfg->n_substeps < 1 || cfg->n_substeps > 64) return fail(PGTT_E_ARG, "pgtt_create: n_substeps out of range");
   if (cfg->method != PGTT_METHOD_PGTT && cfg->method != PGTT_METHOD_BASELINE) return fail(PGTT_E_ARG, "pgtt_create: unknown method");
+  if (cfg->lane_layout != PGTT_LAYOUT_AUTO && cfg->lane_layout != PGTT_LAYOUT_QUAD && cfg->lane_layout != PGTT_LAYOUT_OCT && cfg->lane_layout != PGTT_LAYOUT_HEX)
+    return fail(PGTT_E_ARG, "pgtt_create: lane_layout must be PGTT_LAYOUT_AUTO, _QUAD, _OCT or _HEX");
+  if (cfg->observe_form != PGTT_OBSERVE_FUSED && cfg->observe_form != PGTT_OBSERVE_SPLIT) return fail(PGTT_E_ARG, "pgtt_create: unknown observe_form");
   static const int expect_dof[12] = {9, 10, 11, 6, 7, 8, 15, 16, 17, 12, 13, 14};
   for (int a = 0; a < 12; a++)
     if (model->act_dof[a] != expect_dof[a]) return fail(PGTT_E_ARG, "pgtt_create: actuators must be declared FR,FL,RR,RL on joints FL,FR,RL,RR");
@@ -179,17 +182,11 @@ int pgtt_create(const PgttConfig* cfg, const PgttModel* model, int device, int n
   HIP_TRY(hipSetDevice(device));
   pgtt_env* h = new pgtt_env();
   h->device = device; h->N = num_envs; h->cfg = *cfg; h->model = *model;
-  {
-    // lane layout: PGTT_LAYOUT=quad|oct|hex forces one; default by batch size
-    const char* lay = getenv("PGTT_LAYOUT");
-    h->layout = (lay && !strcmp(lay, "hex")) ? 4 : ((lay && !strcmp(lay, "oct")) ? 2 : ((lay && !strcmp(lay, "quad")) ? 1 : 0));
-    // observe as one kernel (every wave repeats the per-env scalar half: faster while the batch leaves SIMDs idle) or
-    // PGTT_OBSERVE=split: scan + observation rows (env per wave) and rewards / bookkeeping (env per lane) as two kernels.
-    // The fused kernel (four waves per SIMD since its reward terms are evaluated lane-parallel) is faster at every batch
-    // size measured (16384 envs: 0.088 ms against 0.135 ms, 32768: 0.156 against 0.181) and is the default.
-    const char* ob = getenv("PGTT_OBSERVE");
-    h->split_observe = ob && !strcmp(ob, "split");
-  }
+  // lane layout and observe form come through the ABI (PgttConfig.lane_layout / observe_form), never from the environment:
+  // AUTO picks by batch size (launch_physics); the fused observe kernel (four waves per SIMD since its reward terms are evaluated
+  // lane-parallel) is faster than the split form at every batch size measured (16384 envs: 0.088 against 0.135 ms)
+  h->layout = cfg->lane_layout;
+  h->split_observe = cfg->observe_form == PGTT_OBSERVE_SPLIT;
   HIP_TRY(hipMalloc(&h->d_cfg, sizeof(PgttConfig)));
   HIP_TRY(hipMalloc(&h->d_model, sizeof(PgttModel)));
   HIP_TRY(hipMemcpy(h->d_cfg, cfg, sizeof(PgttConfig), hipMemcpyHostToDevice));
@@ -360,6 +357,7 @@ int pgtt_scan(pgtt_handle h, float yaw_override_or_nan, void* stream) {
 
 int pgtt_set_test_overrides(pgtt_handle h, float rng_value_or_nan, int scan_preset) {
   if (!h) return fail(PGTT_E_ARG, "null handle");
+  if (!h->cfg.test_hooks) return fail(PGTT_E_STATE, "pgtt_set_test_overrides: the handle was not created with PgttConfig.test_hooks");
   h->test_rng_fix = rng_value_or_nan; h->test_scan_preset = scan_preset != 0;
   return PGTT_OK;
 }

@@ -12,7 +12,7 @@
 // (deterministic).  No torch types: raw device pointers, the caller's stream.
 #include <hip/hip_runtime.h>
 #include <math.h>
-#include "../../include/pgtt.h"
+#include "../../include/pgtt_train.h"
 
 namespace {
 

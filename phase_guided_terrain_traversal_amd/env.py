@@ -26,9 +26,19 @@ class Joystick:
                  terrain: Optional[np.ndarray] = None, device: str = "cuda:0", params: Optional[torch.Tensor] = None,
                  variant: Optional[torch.Tensor] = None, box_friction: Optional[torch.Tensor] = None,
                  autoreset: bool = False, debug_contacts: bool = False, env_id_offset: int = 0,
-                 model: Optional[Dict[str, Any]] = None):
+                 model: Optional[Dict[str, Any]] = None, layout: Optional[str] = None, observe_form: Optional[str] = None,
+                 test_hooks: bool = False, interval_sums: bool = False):
+        """layout: "auto" | "quad" | "oct" | "hex" lane layout of physics_kernel (PgttConfig.lane_layout; results are bit-identical
+        across batch sizes and shards within one layout); observe_form: "fused" | "split"; test_hooks: allow set_test_overrides
+        (fixture replay only); interval_sums: keep per-env running sums of the step outputs for a logging trainer (PgttBuffers.interval_sums)."""
         self._config = dict(configs.default_config() if config is None else config)
         self._config["autoreset"] = int(autoreset)
+        if layout is not None:
+            self._config["lane_layout"] = layout
+        if observe_form is not None:
+            self._config["observe_form"] = observe_form
+        if test_hooks:
+            self._config["test_hooks"] = True
         self.method = self._config.get("method", "pgtt")     # "pgtt" = go2/joystick_pgtt.py, "baseline" = go2/joystick.py
         self.task = task
         self.num_envs = int(num_envs)
@@ -61,7 +71,9 @@ class Joystick:
         self.buffers["done"] = self.step_block[abi.NMETRIC + 1]
         # per-env running sums of [22 metrics; reward; done] since the trainer last cleared them: a log interval then costs one
         # reduction over the envs (distributed.MetricReducer.reduce_block), not one per step
-        self.buffers["interval_sums"] = torch.zeros((abi.NMETRIC + 2, n), dtype=torch.float32, device=self.device)
+        # (opt-in: 24 read-modify-writes per env-step that only a logging loop such as bench.py consumes and clears)
+        if interval_sums:
+            self.buffers["interval_sums"] = torch.zeros((abi.NMETRIC + 2, n), dtype=torch.float32, device=self.device)
         if params is not None:
             self.buffers["params"] = params.to(self.device, torch.float32).contiguous()
             assert self.buffers["params"].shape == (abi.NPARAM, n)

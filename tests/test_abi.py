@@ -1,4 +1,4 @@
-"""The C-ABI library loads and exports every symbol include/pgtt.h declares; struct layouts agree (no GPU needed)."""
+"""The C-ABI library loads and exports every symbol include/pgtt.h and include/pgtt_train.h declare; struct layouts agree (no GPU needed)."""
 import ctypes as C
 import os
 import re
@@ -11,8 +11,8 @@ from phase_guided_terrain_traversal_amd import abi, configs, mjcf, native
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "pgtt.h")).read()
+def _declared(header="pgtt.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     return sorted(set(re.findall(r"\b(pgtt_[a-z_0-9]+)\s*\(", text)) - {"pgtt_env"})
 
 
@@ -21,8 +21,10 @@ def test_header_symbols_exported():
         pytest.skip("libpgtt.so not built (run __graft_entry__.build())")
     import torch  # noqa: F401  (load torch's HIP runtime first, see native.py)
     lib = C.CDLL(native.LIB_PATH)
-    names = _declared()
-    assert set(names) == set(native.EXPORTS)
+    env_names, train_names = _declared(), _declared("pgtt_train.h")
+    assert set(env_names) == set(native.EXPORTS)
+    assert set(train_names) == set(native.TRAIN_EXPORTS) and not set(train_names) & set(env_names)      # trainer helpers stay out of the env ABI
+    names = env_names + train_names
     for n in names:
         assert hasattr(lib, n), n
     assert lib.pgtt_sizeof_model() == C.sizeof(abi.PgttModel)
@@ -63,6 +65,21 @@ def test_no_cpu_fallback_without_gpu():
         Joystick("flat_terrain", num_envs=8, device="cpu")
 
 
+def test_execution_options_come_through_the_abi_not_the_environment():
+    """lane layout / observe form / test hooks are PgttConfig fields; the library reads no environment variable"""
+    cfg = dict(configs.training_config(), lane_layout="oct", observe_form="split", test_hooks=True)
+    c = abi.config_struct(cfg)
+    assert (c.lane_layout, c.observe_form, c.test_hooks) == (2, 1, 1)
+    c0 = abi.config_struct(configs.training_config())
+    assert (c0.lane_layout, c0.observe_form, c0.test_hooks) == (0, 0, 0)
+    text = open(os.path.join(ROOT, "include", "pgtt.h")).read()
+    for name, val in (("AUTO", 0), ("QUAD", 1), ("OCT", 2), ("HEX", 4)):
+        assert int(re.search(rf"PGTT_LAYOUT_{name}\s*=\s*(\d+)", text).group(1)) == val == abi.LAYOUTS[name.lower()]
+    for f in os.listdir(os.path.join(ROOT, "phase_guided_terrain_traversal_amd", "csrc")):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(ROOT, "phase_guided_terrain_traversal_amd", "csrc", f)).read(), f
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "phase_guided_terrain_traversal_amd")
     for dp, _, files in os.walk(pkg):
@@ -84,6 +101,15 @@ def test_model_struct_roundtrip():
     assert c.n_substeps == 4 and abs(c.cmd_u_max[2] - 1.0) < 1e-7 and abs(c.gait_freq[1] - 3) < 1e-7
     assert abs(c.reward_scale[abi.REWARD_KEYS.index("feet_phase")] - 0.5) < 1e-7
     assert abs(c.reward_scale[abi.REWARD_KEYS.index("contact")] - 2.0) < 1e-7
+
+
+def test_evaluation_config_has_the_reference_evaluators_command_range():
+    """training/evaluate.py:127-129 evaluates on u_max = [0.4, 0.4, 0.7], gait_freq = [1, 3] - not on training's +-[0.6, 0.6, 1.0]"""
+    for method in ("pgtt", "baseline"):
+        c = configs.evaluation_config(method)
+        assert c["command_config"]["u_max"] == [0.4, 0.4, 0.7] and c["command_config"]["u_min"] == [-0.4, -0.4, -0.7] and c["gait_freq"] == [1, 3]
+        assert c["method"] == method and c["reward_config"] == configs.training_config(method)["reward_config"]
+    assert configs.training_config()["command_config"]["u_max"] == [0.6, 0.6, 1.0]
 
 
 def test_tools_and_entry_points_compile():

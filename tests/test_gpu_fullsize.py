@@ -77,10 +77,9 @@ def test_masked_reset_leaves_other_envs_untouched():
 
 
 @pytest.mark.parametrize("observe", ["fused", "split"])
-def test_episode_and_autoreset_semantics(observe, monkeypatch):
-    monkeypatch.setenv("PGTT_OBSERVE", observe)
+def test_episode_and_autoreset_semantics(observe):
     cfg = configs.with_overrides(configs.training_config(), episode_length=7)
-    env, _, _ = make(n=512, cfg=cfg, variant=np.zeros(512, dtype=np.int32))
+    env, _, _ = make(n=512, cfg=cfg, variant=np.zeros(512, dtype=np.int32), observe_form=observe)
     env.reset(seed=5)
     first_state = env.buffers["first_state"].clone(); first_obs = env.buffers["first_obs"].clone()
     assert torch.equal(first_state, env.buffers["state"][:abi.S_CMD])
@@ -234,20 +233,16 @@ def test_configs3_wfc_dr_8192_full_size():
     terrain = create_random_matrix(100, 100, 5, 0.05, 0.13, seed=3)
     model = mjcf.load_model("stairs")
 
-    def build(cnt, off):
+    def build(cnt, off, layout=None):
         out = domain_randomize(model, cnt, seed=3, terrain=terrain, env_id_offset=off)
-        return Joystick("stairs", configs.training_config(), num_envs=cnt, terrain=terrain, device="cuda:0", autoreset=True, env_id_offset=off,
+        return Joystick("stairs", configs.training_config(), num_envs=cnt, terrain=terrain, device="cuda:0", autoreset=True, env_id_offset=off, layout=layout,
                         variant=torch.from_numpy(out["variant"]), params=torch.from_numpy(out["params"]), box_friction=torch.from_numpy(out["box_friction"])), out
 
     def acts(k, cnt, off):
         g = np.random.Generator(np.random.Philox(key=[9, k]))
         return torch.from_numpy(np.tanh(g.normal(size=(n, 12)) * 0.6).astype(np.float32)[off:off + cnt]).cuda()
 
-    os.environ["PGTT_LAYOUT"] = "oct"           # the shards must run the layout the full batch selects by itself
-    try:
-        h0, _ = build(n // 2, 0); h1, _ = build(n // 2, n // 2)
-    finally:
-        del os.environ["PGTT_LAYOUT"]
+    h0, _ = build(n // 2, 0, "oct"); h1, _ = build(n // 2, n // 2, "oct")       # the shards pin the layout the full batch selects by itself (PgttConfig.lane_layout)
     a, dr = build(n, 0); b, _ = build(n, 0)
     for e in (a, b, h0, h1):
         e.reset(seed=5)
@@ -317,11 +312,10 @@ dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("observe", ["fused", "split"])
-def test_interval_sums_equal_the_per_step_sums(observe, monkeypatch):
+def test_interval_sums_equal_the_per_step_sums(observe):
     """buffers["interval_sums"]: the running per-env sums of [22 metrics; reward; done] kept by the step kernels are the sums of
     the per-step outputs (same additions in the same order: bitwise), AutoReset on, until the caller clears the block"""
-    monkeypatch.setenv("PGTT_OBSERVE", observe)
-    env, _, _ = make(n=1024, level="level13")
+    env, _, _ = make(n=1024, level="level13", observe_form=observe, interval_sums=True)
     env.reset(seed=2)
     ref = torch.zeros_like(env.buffers["interval_sums"])
     for k in range(25):
@@ -349,7 +343,7 @@ def test_configs4_one_rank_of_the_curriculum_shard():
         assert (lo, hi) == (4096 * r, 4096 * (r + 1))
         terrain = np.load(os.path.join(ASSETS, f"level{lev}.npy"))
         variant = np.random.Generator(np.random.Philox(key=[2, 0])).integers(0, terrain.shape[0], 32768).astype(np.int32)[lo:hi]
-        env, _, _ = make(n=N, off=lo, level=f"level{lev}", variant=variant)
+        env, _, _ = make(n=N, off=lo, level=f"level{lev}", variant=variant, interval_sums=True)
         assert env.observation_size == {"state": 171, "privileged_state": 215} and env.action_size == 12 and abs(env.dt - 0.02) < 1e-9
         assert env.xml_path.endswith("go2_stairs.json") and env.mj_model["_nbox"] == 100
         env.reset(seed=7)

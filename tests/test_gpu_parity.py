@@ -17,6 +17,10 @@ from phase_guided_terrain_traversal_amd import abi, configs, mjcf
 ASSETS = os.path.join(os.path.dirname(mjcf.__file__), "assets")
 
 
+# execution options of the envs this module builds (PgttConfig.lane_layout / observe_form), set by the fixtures below
+EXEC = {"layout": None, "observe_form": None}
+
+
 def make_pair(task, n, terrain=None, noise=1.0, autoreset=False, dr=False, method="pgtt", ctrl_dt=None):
     from phase_guided_terrain_traversal_amd.env import Joystick
     cfg = configs.with_overrides(configs.training_config(method), **{"noise_config.level": noise})
@@ -38,7 +42,7 @@ def make_pair(task, n, terrain=None, noise=1.0, autoreset=False, dr=False, metho
             variant = out["variant"]
     if variant is not None:
         kw["variant"] = torch.from_numpy(variant)
-    env = Joystick(task, cfg, num_envs=n, terrain=terrain, device="cuda:0", autoreset=autoreset, debug_contacts=True, **kw)
+    env = Joystick(task, cfg, num_envs=n, terrain=terrain, device="cuda:0", autoreset=autoreset, debug_contacts=True, **EXEC, **kw)
     cfg2 = dict(cfg); cfg2["autoreset"] = int(autoreset)
     cs, ms = abi.config_struct(cfg2), abi.model_struct(model)
     hb = oracle.HostBuffers(n, with_params=dr, with_variant=variant is not None, with_box_friction=bf is not None, method=method)
@@ -197,10 +201,11 @@ def test_flat_parity(layout):
 
 
 @pytest.fixture(params=["quad", "oct", "hex"])
-def layout(request, monkeypatch):
+def layout(request):
     """the three lane layouts of physics_kernel (pgtt_physics_quad.hip.h): 16, 8 or 4 envs per wave"""
-    monkeypatch.setenv("PGTT_LAYOUT", request.param)
-    return request.param
+    EXEC["layout"] = request.param
+    yield request.param
+    EXEC["layout"] = None
 
 
 def test_level4_parity(layout):
@@ -261,13 +266,16 @@ def test_baseline_method_parity():
     env.close()
 
 
-def test_split_observe_parity(monkeypatch):
+def test_split_observe_parity():
     """observe as two kernels (scan + observation rows per wave, rewards / bookkeeping / AutoReset per lane), the path
     taken from 16 k envs: same parity bar, AutoReset included"""
-    monkeypatch.setenv("PGTT_OBSERVE", "split")
-    terrain = np.load(os.path.join(ASSETS, "terrains", "level13.npy"))
-    run_parity("stairs", 128, terrain, steps=40, dr=True, autoreset=True)
-    run_parity("flat_terrain", 100, None, steps=20, autoreset=True, method="baseline")
+    EXEC["observe_form"] = "split"
+    try:
+        terrain = np.load(os.path.join(ASSETS, "terrains", "level13.npy"))
+        run_parity("stairs", 128, terrain, steps=40, dr=True, autoreset=True)
+        run_parity("flat_terrain", 100, None, steps=20, autoreset=True, method="baseline")
+    finally:
+        EXEC["observe_form"] = None
 
 
 def test_library_refuses_without_bind():

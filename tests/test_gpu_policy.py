@@ -50,6 +50,44 @@ def test_box_tops_are_solid_under_hard_landings():
     assert abs(one["base_z"] - flat["base_z"] - 0.06) < 0.004
 
 
+def _flip_stats(lib_name):
+    """tools/gpu_flip_stats.py in its own process against the build `lib_name` of the package directory (PGTT_LIB is read when the
+    library is first loaded)"""
+    import json, subprocess, sys
+    from phase_guided_terrain_traversal_amd import mjcf
+    pkg = os.path.dirname(mjcf.__file__)
+    lib = os.path.join(pkg, lib_name)
+    assert os.path.exists(lib), f"{lib} missing: __graft_entry__.build() makes it (make -C csrc flip)"
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(pkg), "tools", "gpu_flip_stats.py"), "level13", "2048", "500"],
+                       env=dict(os.environ, PGTT_LIB=lib), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_sphere_box_decision_is_regression_guarded_by_the_flip_build():
+    """the literal recalled `_sphere_convex` takes the contact normal from normalize(pt - centre), which flips the frame once
+    the sphere CENTRE is inside the box (penetration > radius = 17.5 mm).  The product keeps the inward normal; which of the two the
+    authors' MJX build does cannot be read off the reference, the reference's own statistics decide it.  This test keeps the decision
+    honest: the SAME rollouts in the -DPGTT_SPHERE_CONVEX_FLIP build (libpgtt_flip.so, same sources, one switch) must FAIL what the
+    product passes - the contact duty of policy177's normaliser (0.444 over 443 M samples of the reference's simulator: product 0.441,
+    flip build 0.55-0.64), the base height on a 6 cm slab (+ 6 cm solid, + 2 cm sinking) - and the run records how often a box
+    contact is deeper than the radius at all (profiles/r03_penetration_hist.txt)."""
+    prod, flip = _flip_stats("libpgtt.so"), _flip_stats("libpgtt_flip.so")
+    print("product", {k: prod[k] for k in ("contact_duty", "slab_base_gain_m", "frac_deeper_than_radius", "max_penetration_m", "std_ratio")})
+    print("flip   ", {k: flip[k] for k in ("contact_duty", "slab_base_gain_m", "frac_deeper_than_radius", "max_penetration_m", "std_ratio")})
+    ref = prod["contact_duty_ref"]
+    assert abs(ref - 0.444) < 0.002
+    # the product reproduces the reference's statistics ...
+    assert abs(prod["contact_duty"] - ref) < 0.012 and abs(prod["slab_base_gain_m"] - 0.06) < 0.004 and prod["slab_survival"] > 0.99
+    assert abs(prod["air_time_mean"] / prod["air_time_mean_ref"] - 1) < 0.04
+    # ... the literal variant does not: feet sink through box tops
+    assert flip["contact_duty"] - ref > 0.05, flip["contact_duty"]
+    assert flip["slab_base_gain_m"] < 0.045, flip["slab_base_gain_m"]
+    assert flip["std_ratio"]["gravity"] > prod["std_ratio"]["gravity"] + 0.15           # the trunk tilts far more than in the reference's runs
+    # the regime exists on the training distribution: some box contacts of the PRODUCT run are deeper than the foot radius
+    assert prod["box_contacts"] > 100000 and prod["box_contacts_deeper_than_radius"] > 0
+
+
 def _stat_rows(level, **kw):
     import numpy as np
     from gpu_policy_stats import compare, rollout_stats

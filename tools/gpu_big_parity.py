@@ -5,11 +5,11 @@ sys.path.insert(0, os.getcwd())
 import tests.test_gpu_parity as T
 terrain = np.load(os.path.join(T.ASSETS, "terrains", "level4.npy"))
 for lay in (sys.argv[1:] or ["hex", "quad", "oct"]):
-    os.environ["PGTT_LAYOUT"] = lay
+    T.EXEC["layout"] = lay
     st = T.run_parity("stairs", 1024, terrain, steps=100)
     print(lay, "OK", {k: st[k] for k in ("frac_gpu_1e4", "frac_fp_1e4", "well_frac", "well_flag_mismatch", "well_set_mismatch")}, st["well_violations"])
 t13 = np.load(os.path.join(T.ASSETS, "terrains", "level13.npy"))
 for lay in (sys.argv[1:] or ["hex", "oct"]):
-    os.environ["PGTT_LAYOUT"] = lay
+    T.EXEC["layout"] = lay
     st = T.run_parity("stairs", 512, t13, steps=80, dr=True, autoreset=True)
     print(lay, "level13 dr OK", {k: st[k] for k in ("frac_gpu_1e4", "frac_fp_1e4", "well_frac", "well_flag_mismatch", "well_set_mismatch")}, st["well_violations"])

@@ -7,8 +7,7 @@ from phase_guided_terrain_traversal_amd.policy import load_policy
 pi = load_policy("policy177")
 ref_m = np.load("phase_guided_terrain_traversal_amd/assets/policies/policy177.npz")
 for lay, n in (("hex", 4096), ("oct", 8192)):
-    os.environ["PGTT_LAYOUT"] = lay
-    out = G.rollout_stats("level13", n=n, steps=600, stochastic=True)
+    out = G.rollout_stats("level13", n=n, steps=600, stochastic=True, layout=lay)
     mean, std = out[0], out[1]
     rows = G.compare(mean, std, ref_m["mean_priv"], ref_m["std_priv"])
     print(lay, n, "survival/extra:", out[2:] if len(out) > 2 else "")

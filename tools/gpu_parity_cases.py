@@ -38,7 +38,7 @@ def find(task, n, terrain, steps, ctrl_dt):
 if __name__ == "__main__":
     A = os.path.join(ROOT, "phase_guided_terrain_traversal_amd", "assets", "terrains")
     ctrl_dt = float(sys.argv[2]) if len(sys.argv) > 2 else 0.005
-    os.environ.setdefault("PGTT_LAYOUT", "hex")
+    P.EXEC["layout"] = "hex"
     out = {}
     for name, task, terr in (("flat", "flat_terrain", None), ("level4", "stairs", np.load(os.path.join(A, "level4.npy")))):
         cs = find(task, 512, terr, 60, ctrl_dt)

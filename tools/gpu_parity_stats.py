@@ -72,11 +72,11 @@ if __name__ == "__main__":
     A = os.path.join(ROOT, "phase_guided_terrain_traversal_amd", "assets", "terrains")
     res = {}
     for lay in ("hex", "quad"):
-        os.environ["PGTT_LAYOUT"] = lay
+        P.EXEC["layout"] = lay
         res[f"flat_{lay}"] = summarise(f"flat_{lay}", *collect("flat_terrain", 512, None, 60))
         res[f"level4_{lay}"] = summarise(f"level4_{lay}", *collect("stairs", 512, np.load(os.path.join(A, "level4.npy")), 60))
         res[f"level13_dr_{lay}"] = summarise(f"level13_dr_{lay}", *collect("stairs", 256, np.load(os.path.join(A, "level13.npy")), 60, dr=True, autoreset=True))
-    os.environ["PGTT_LAYOUT"] = "hex"
+    P.EXEC["layout"] = "hex"
     res["flat_1substep"] = summarise("flat_1substep", *collect("flat_terrain", 512, None, 60, ctrl_dt=0.005))
     res["level4_1substep"] = summarise("level4_1substep", *collect("stairs", 512, np.load(os.path.join(A, "level4.npy")), 60, ctrl_dt=0.005))
     if len(sys.argv) > 1:

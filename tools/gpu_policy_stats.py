@@ -22,14 +22,15 @@ BLOCKS_BASELINE = [("gyro", 0, 3), ("gravity", 3, 6), ("joint pos - default", 6,
                    ("feet air time", 199, 203)]
 
 
-def rollout_stats(level="level13", n=2048, steps=700, seed=0, dr=True, stochastic=False, kv=None, policy="policy177", method="pgtt"):
+def rollout_stats(level="level13", n=2048, steps=700, seed=0, dr=True, stochastic=False, kv=None, policy="policy177", method="pgtt", layout=None, hist=None):
+    """hist: optional dict that receives the histogram of max(0, -dist) over the box contacts met during the rollout (see __main__)"""
     assets = os.path.join(os.path.dirname(mjcf.__file__), "assets")
     flat = level == "flat"
     terrain = None if flat else np.load(os.path.join(assets, "terrains", level + ".npy"))
     model = mjcf.load_model("flat_terrain" if flat else "stairs")
     if kv is not None:
         model = mjcf.with_bias_velocity(model, kv)
-    kw = {"model": model}
+    kw = {"model": model, "layout": layout, "debug_contacts": hist is not None}
     if dr and flat:
         kw["params"] = torch.from_numpy(domain_randomize(model, n, seed=5)["params"])
     elif flat:
@@ -45,6 +46,14 @@ def rollout_stats(level="level13", n=2048, steps=700, seed=0, dr=True, stochasti
     s1 = torch.zeros(env.observation_size["privileged_state"], device="cuda:0", dtype=torch.float64); s2 = torch.zeros_like(s1); cnt = 0
     for k in range(steps):
         env.step(pi.sample(env.buffers["obs_state"]) if stochastic else pi(env.buffers["obs_state"]))
+        if hist is not None and k >= 100:
+            # box-contact slots 4..7 of the debug record (foot, geom >= 0 = box index, dist): penetration depth of every box contact
+            dist = env.buffers["dbg_dist"][:, 4:8]; geom = env.buffers["dbg_contact"].view(n, abi.NCON, 2)[:, 4:8, 1]
+            pen = (-dist[geom >= 0]).clamp(min=0)
+            hist["counts"] = hist.get("counts", 0) + torch.histc(pen, bins=len(hist["edges"]) - 1, min=float(hist["edges"][0]), max=float(hist["edges"][-1])).cpu().numpy()
+            hist["n"] = hist.get("n", 0) + int(pen.numel()); hist["over_radius"] = hist.get("over_radius", 0) + int((pen > 0.0175).sum()); hist["max"] = max(hist.get("max", 0.0), float(pen.max()) if pen.numel() else 0.0)
+            pd0 = env.buffers["dbg_dist"][:, 0:4]
+            hist["plane_n"] = hist.get("plane_n", 0) + int((pd0 < 0).sum()); hist["plane_over_radius"] = hist.get("plane_over_radius", 0) + int((pd0 < -0.0175).sum())
         if k >= 100:
             p = env.buffers["obs_priv"].double()
             s1 += p.mean(0); s2 += (p * p).mean(0); cnt += 1

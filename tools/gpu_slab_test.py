@@ -1,7 +1,8 @@
 """Does a foot stand ON a box?  policy177 walks onto one wide slab of a given height; prints the steady trunk / foot heights over the slab
 against the flat-ground values (the experiment behind the sphere-box fix)."""
 import os, sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, "tools"))
 import numpy as np, torch
 from phase_guided_terrain_traversal_amd import abi, configs, mjcf
 from phase_guided_terrain_traversal_amd.env import Joystick
@@ -31,7 +32,8 @@ def tiles(h, size=0.5):   # the same flat surface at height h, but made of many 
         for j in range(10):
             t[0, k] = [(i - 4.5) * size, (j - 4.5) * size, h/2, 1, 0, 0, 0, size/2, size/2, h/2]; k += 1
     return t
-print("flat plane      ", run(None, "flat_terrain"))
-print("one slab 6 cm   ", run(slab(0.06)))
-print("tiles 0.5 m 6 cm", run(tiles(0.06)))
-print("tiles 0.3 m 6 cm", run(tiles(0.06, 0.3), steps=250))
+if __name__ == "__main__":
+    print("flat plane      ", run(None, "flat_terrain"))
+    print("one slab 6 cm   ", run(slab(0.06)))
+    print("tiles 0.5 m 6 cm", run(tiles(0.06)))
+    print("tiles 0.3 m 6 cm", run(tiles(0.06, 0.3), steps=250))

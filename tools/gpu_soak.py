@@ -8,7 +8,6 @@ from phase_guided_terrain_traversal_amd.randomize import domain_randomize
 from phase_guided_terrain_traversal_amd import mjcf
 assets = "phase_guided_terrain_traversal_amd/assets/terrains"
 for lay in (sys.argv[1:] or ["hex", "quad", "oct"]):
-    os.environ["PGTT_LAYOUT"] = lay
     for level, dr in (("level13", True), ("level4", False)):
         terrain = np.load(f"{assets}/{level}.npy"); n = 8192 if lay == "oct" else 4096
         kw = {}
@@ -17,7 +16,7 @@ for lay in (sys.argv[1:] or ["hex", "quad", "oct"]):
             kw = {"variant": torch.from_numpy(out["variant"]), "params": torch.from_numpy(out["params"]), "box_friction": torch.from_numpy(out["box_friction"])}
         else:
             kw = {"variant": torch.from_numpy(np.random.default_rng(1).integers(0, terrain.shape[0], n).astype(np.int32))}
-        env = Joystick("stairs", configs.training_config(), num_envs=n, terrain=terrain, device="cuda:0", autoreset=True, **kw)
+        env = Joystick("stairs", configs.training_config(), num_envs=n, terrain=terrain, device="cuda:0", autoreset=True, layout=lay, **kw)
         env.reset(seed=9)
         g = torch.Generator(device="cuda").manual_seed(3)
         dones = 0.0; bad = 0

@@ -3,18 +3,18 @@
 # counters only) -> gpurun_out/$ROUND_TAG/ ; tools/collect_profiles.py copies the summaries into profiles/
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/${ROUND_TAG:-r02}; mkdir -p $O
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/driver_cmd_bench.json 2>$O/driver_cmd_bench.err; echo "driver command rc=$?"; cat $O/driver_cmd_bench.json
-python bench.py > $O/bench_level4.json 2>$O/bench_level4.err
-python bench.py --workload flat --no-cpu-baseline > $O/bench_flat.json 2>/dev/null
-python bench.py --workload wfc_dr --envs 8192 --no-cpu-baseline > $O/bench_wfc_dr_8192.json 2>/dev/null
-PGTT_LAYOUT=quad python bench.py --no-cpu-baseline > $O/bench_level4_quad.json 2>/dev/null
-PGTT_LAYOUT=quad python bench.py --workload wfc_dr --envs 8192 --no-cpu-baseline > $O/bench_wfc_dr_8192_quad.json 2>/dev/null
-python bench.py --envs 8192 --no-cpu-baseline > $O/bench_level4_8192.json 2>/dev/null
-python bench.py --envs 32768 --no-cpu-baseline > $O/bench_level4_32768.json 2>/dev/null
-python bench.py --workload flat --envs 16384 --no-cpu-baseline > $O/bench_flat_16384.json 2>/dev/null
-rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python bench.py --no-cpu-baseline > $O/kt_bench.json 2>/dev/null
-for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c -d $O/pmc_$c -o p --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1; done
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU -d $O/pmc_sq -o p --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -o p --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+python bench.py --no-other-configs > $O/bench_level4.json 2>$O/bench_level4.err
+python bench.py --workload flat --no-cpu-baseline --no-other-configs > $O/bench_flat.json 2>/dev/null
+python bench.py --workload wfc_dr --envs 8192 --no-cpu-baseline --no-other-configs > $O/bench_wfc_dr_8192.json 2>/dev/null
+python bench.py --layout quad --no-cpu-baseline --no-other-configs > $O/bench_level4_quad.json 2>/dev/null
+python bench.py --layout quad --workload wfc_dr --envs 8192 --no-cpu-baseline --no-other-configs > $O/bench_wfc_dr_8192_quad.json 2>/dev/null
+python bench.py --envs 8192 --no-cpu-baseline --no-other-configs > $O/bench_level4_8192.json 2>/dev/null
+python bench.py --envs 32768 --no-cpu-baseline --no-other-configs > $O/bench_level4_32768.json 2>/dev/null
+python bench.py --workload flat --envs 16384 --no-cpu-baseline --no-other-configs > $O/bench_flat_16384.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python bench.py --no-cpu-baseline --no-other-configs > $O/kt_bench.json 2>/dev/null
+for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c -d $O/pmc_$c -o p --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > /dev/null 2>&1; done
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU -d $O/pmc_sq -o p --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -o p --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > /dev/null 2>&1
 python tools/pmc_summary.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_sq $O/pmc_mfma > $O/pmc_summary.txt
 cp $O/kt/*kernel_stats.csv $O/kernel_stats.csv
 for f in $O/bench_*.json $O/driver_cmd_bench.json $O/kt_bench.json; do python -c "import sys,json; d=json.load(open('$f')); print('$f', d['value'], d['ms_per_step'], d['kernels_ms'], d.get('wall_over_kernels'))"; done
