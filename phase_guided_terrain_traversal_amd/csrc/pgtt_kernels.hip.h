@@ -359,11 +359,13 @@ PG_INL float wave_min(float v) {
 // axis-parallel component gives 1 / (+-0) = +-inf and the same +-inf / NaN face parameters as the division.
 struct RayBox { float il[3]; bool upright; };
 PG_INL RayBox ray_box_prepare(const TerrainBox& tb) {
-  // upright: the box z axis is the world z axis (every shipped / generated terrain: boxes are only turned about z).  The ray
-  // then runs along the box z axis, the four side faces give +-inf / NaN parameters and are never valid, and the generic
-  // test reduces - bit for bit - to its two z faces.
+  // upright: the box z axis is along the world z axis (every shipped / generated terrain: boxes are only turned about z).  The ray
+  // then runs along the box z axis: lv = (-0, -0, -m22), the four side faces get the parameters (side - lp) * rcp(-0) = +-inf / NaN
+  // and hit points lp + x * (-0) = NaN, so they are never valid, while on the two z faces p0 = lp0 + x * (-0) = lp0 exactly - the generic
+  // test reduces, bit for bit, to its two z faces.  m22 itself need not be 1: the tables hold float32 quaternions, and a box turned by
+  // 90 degrees (0.70710677, 0, 0, 0.70710677) has m22 = w^2 + z^2 = 0.99999994 (half of the boxes of the level files).
   return RayBox{{__builtin_amdgcn_rcpf(-tb.m20), __builtin_amdgcn_rcpf(-tb.m21), __builtin_amdgcn_rcpf(-tb.m22)},
-                tb.m20 == 0.f && tb.m21 == 0.f && fabsf(tb.m22) == 1.0f};
+                tb.m20 == 0.f && tb.m21 == 0.f && tb.m22 != 0.f};
 }
 PG_INL float ray_box_down(const TerrainBox& tb, const RayBox& rb, V3 p) {
   V3 rel = p - v3(tb.px, tb.py, tb.pz);
@@ -566,6 +568,20 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
   __shared__ float sh_obs[PGTT_OBS + PGTT_PRIV + 2];
   __shared__ float sh_act[12];
 
+  // The terrain records of the env's variant do not depend on the state: lane j requests the first and the last 16 bytes of the
+  // 80-byte records of boxes j and j + 64 (centre, world-AABB half extents: what the cull needs) BEFORE the state rows are waited for,
+  // so the two round trips overlap - and the middle of a surviving record is then a cache hit
+  const TerrainBox* __restrict__ boxes = nullptr;
+  float4 brec[2][2];
+  if (HAS_TERRAIN) {
+    const int v = a.buf.variant ? a.buf.variant[e] : 0;
+    boxes = a.terrain + (long)v * a.B;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int b = min(lane + 64 * h, a.B - 1);
+      brec[h][0] = reinterpret_cast<const float4*>(boxes + b)[0]; brec[h][1] = reinterpret_cast<const float4*>(boxes + b)[4];
+    }
+  }
   for (int r = lane; r < PGTT_NSTATE; r += 64) sh_st[r] = S[r * (long)N + e];
   for (int r = lane; r < PGTT_NFRAME; r += 64) sh_fr[r] = a.buf.frame[r * (long)N + e];
   if (OMODE == OBS_STEP && lane < 12) sh_act[lane] = action[(long)e * 12 + lane];
@@ -603,28 +619,67 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
     hit[h] = x >= 0.f ? x : INFINITY;
   }
   if (HAS_TERRAIN) {
-    const int v = a.buf.variant ? a.buf.variant[e] : 0;
-    const TerrainBox* __restrict__ boxes = a.terrain + (long)v * a.B;
     // cull, lane-parallel: lane j looks at boxes j and j + 64: world AABB of the box against the scan footprint, a
     // rectangle of half-sides (hx, hy) turned by the yaw - the four separating axes of a rectangle / AABB pair in the
     // plane, with 1 mm of slack (a vertical ray can only hit a box whose footprint contains it, so dropping the boxes
-    // that do not overlap the rectangle changes no hit).  The ballots give the boxes worth a ray test, which are then
-    // visited with wave-uniform loads; min() over the hits does not depend on the visiting order.
+    // that do not overlap the rectangle changes no hit).  min() over the hits does not depend on the visiting order.
     const float hx = 0.5f * (PGTT_SCAN_H - 1) * fabsf(cfg->scan_dist_x) + 1e-3f, hy = 0.5f * (PGTT_SCAN_W - 1) * fabsf(cfg->scan_dist_y) + 1e-3f;
     const float acy = fabsf(cy), asy = fabsf(sy);
+    // The survivors' records are COMPACTED into LDS (slot = number of surviving boxes before this one) and the ray loop reads them from
+    // there through wave-uniform addresses, the next record requested while the current one is tested: no scalar-memory round trip
+    // per box any more (a wave used to wait ~0.3 us for every 80-byte record; the slowest waves of a launch are those that stand among
+    // many boxes).  kScanSlots survivors fit; further ones (never on the shipped terrains) are read from the table as before.
+    constexpr int kScanSlots = 40;
+    __shared__ float4 sh_box[kScanSlots * 5];
     unsigned long long todo[2];
+    int nsurv = 0;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const int b = lane + 64 * h;
       bool reach = false;
       if (b < a.B) {
-        const float4 A = reinterpret_cast<const float4*>(boxes + b)[0];
-        const float4 H = reinterpret_cast<const float4*>(boxes + b)[4];
+        const float4 A = brec[h][0], H = brec[h][1];
         const float dx = A.x - bx, dy = A.y - by;
         reach = (fabsf(dx) <= H.x + hx * acy + hy * asy) & (fabsf(dy) <= H.y + hx * asy + hy * acy) &
                 (fabsf(dx * cy + dy * sy) <= hx + H.x * acy + H.y * asy) & (fabsf(dy * cy - dx * sy) <= hy + H.x * asy + H.y * acy);
       }
-      todo[h] = __ballot(reach);
+      const unsigned long long mk = __ballot(reach);
+      const int slot = nsurv + __popcll(mk & ((1ull << lane) - 1ull));
+      if (reach && slot < kScanSlots) {
+        sh_box[slot * 5 + 0] = brec[h][0]; sh_box[slot * 5 + 4] = brec[h][1];
+#pragma unroll
+        for (int q = 1; q < 4; q++) sh_box[slot * 5 + q] = reinterpret_cast<const float4*>(boxes + b)[q];
+      }
+      // boxes beyond the slots: the highest set bits of this half (slot order = bit order)
+      int over = nsurv + __popcll(mk) - kScanSlots;
+      unsigned long long rest = 0ull, t = mk;
+      while (over > 0 && t != 0ull) { const int hb = 63 - __builtin_clzll(t); rest |= 1ull << hb; t &= ~(1ull << hb); over--; }
+      todo[h] = rest;
+      nsurv += __popcll(mk);
+    }
+    __syncthreads();
+    const int nslot = min(nsurv, kScanSlots);
+    auto load_slot = [&](int i, float4 (&r)[5]) {
+#pragma unroll
+      for (int q = 0; q < 5; q++) r[q] = sh_box[i * 5 + q];
+    };
+    auto test_box = [&](const float4 (&r)[5]) {
+      TerrainBox tb;
+      tb.px = r[0].x; tb.py = r[0].y; tb.pz = r[0].z; tb.rb = r[0].w; tb.sx = r[1].x; tb.sy = r[1].y; tb.sz = r[1].z; tb.m00 = r[1].w;
+      tb.m01 = r[2].x; tb.m02 = r[2].y; tb.m10 = r[2].z; tb.m11 = r[2].w; tb.m12 = r[3].x; tb.m20 = r[3].y; tb.m21 = r[3].z; tb.m22 = r[3].w;
+      tb.hx = r[4].x; tb.hy = r[4].y; tb.hz = r[4].z; tb.pad = r[4].w;
+      RayBox rb = ray_box_prepare(tb);
+      rb.upright = __builtin_amdgcn_readfirstlane((int)rb.upright) != 0;      // the record is the same in every lane: keep the branch scalar
+#pragma unroll
+      for (int k = 0; k < 2; k++) hit[k] = fminf(hit[k], ray_box_down(tb, rb, org[k]));
+    };
+    float4 cur[5], nxt[5];
+    if (nslot > 0) load_slot(0, cur);
+    for (int i = 0; i < nslot; i++) {
+      if (i + 1 < nslot) load_slot(i + 1, nxt);
+      test_box(cur);
+#pragma unroll
+      for (int q = 0; q < 5; q++) cur[q] = nxt[q];
     }
 #pragma unroll
     for (int h = 0; h < 2; h++) {

@@ -33,6 +33,12 @@ namespace pgtt {
 #define PG_SUBS 1
 #endif
 constexpr int kSubs = PG_SUBS;
+// this translation unit's kernel has box terrain (one TU per physics_kernel variant, pgtt_physics_inst.hip); 0 where the header is only parsed
+#ifdef PG_TERRAIN
+constexpr bool kTerrainTU = PG_TERRAIN != 0;
+#else
+constexpr bool kTerrainTU = false;
+#endif
 constexpr int kEnvsPerWave = 16 / PG_SUBS;
 static_assert(PG_SUBS == 1 || PG_SUBS == 2 || PG_SUBS == 4, "lane layouts: quad, oct, hex");
 // who am I: sub-lane of the leg, leg of the env, env of the wave, lane of the env, LDS column of the (env, leg) pair
@@ -1429,8 +1435,10 @@ struct QSolver {
       // hex layout: sub-lane r evaluates row r of every constraint of its leg (limit row r < 3, pyramid row r of the
       // plane contact and of each box slot); the sums below run over all 16 lanes of the env
       const int r = threadIdx.x & 3;
-      if (any_lim || any_con0) ls_row2d<NA, COST>(hx_ja, hx_jv, hx_D, al, q);       // own (limit row, plane row), picked once per search
-      if (nslots > 0) ls_row2d<NA, COST>(ls_ja[0], ls_jv[0], ls_D[0], al, q);
+      // On box terrain these two row pairs are live in nearly every wave: evaluated unconditionally there (rows that are not in use hold
+      // zeros and add exact zeros) - a not-taken branch costs a one-wave SIMD ~10 cycles, and a round has a dozen instructions per pair
+      if (kTerrainTU || any_lim || any_con0) ls_row2d<NA, COST>(hx_ja, hx_jv, hx_D, al, q);       // own (limit row, plane row), picked once per search
+      if (kTerrainTU || nslots > 0) ls_row2d<NA, COST>(ls_ja[0], ls_jv[0], ls_D[0], al, q);
       if (nslots > 2) ls_row2d<NA, COST>(ls_ja[1], ls_jv[1], ls_D[1], al, q);
     }
 #pragma unroll
@@ -1563,9 +1571,11 @@ struct QSolver {
     //   in_bracket(x, y) = (x.d0 < y.d0 < 0) or (x.d0 > y.d0 > 0),
     // tried in a fixed order, each test against the already updated end.  With u = d0 * sign(x.d0) (exact) this is a
     // running "0 < u_y < u_x": a chain over ONE scalar; the winner's four fields are picked once at the end.
-    auto tighten = [](const LSPoint& x, const LSPoint& c1, const LSPoint& c2, const LSPoint& c3, bool& moved) {
+    // `frozen`: the env has left the search (its lanes only keep the wave company): threshold 0, nothing enters, the end stays as it is -
+    // one select instead of an exec-mask region (save / branch / restore / branch, ~45 cycles of a one-wave SIMD) round the update
+    auto tighten = [](const LSPoint& x, const LSPoint& c1, const LSPoint& c2, const LSPoint& c3, bool frozen, bool& moved) {
       const float sg = x.d0 > 0.f ? 1.0f : -1.0f;
-      float u = x.d0 * sg;                          // |x.d0| (0 if x.d0 == 0: nothing can enter the bracket)
+      float u = frozen ? 0.f : x.d0 * sg;           // |x.d0| (0 if x.d0 == 0: nothing can enter the bracket)
       const float u1 = c1.d0 * sg, u2 = c2.d0 * sg, u3 = c3.d0 * sg;
       const bool k1 = (u1 > 0.f) & (u1 < u); u = k1 ? u1 : u;
       const bool k2 = (u2 > 0.f) & (u2 < u); u = k2 ? u2 : u;
@@ -1597,9 +1607,10 @@ struct QSolver {
       LSPoint pt[3];
       ls_points<3, false>(al3, jv_lim, jv0, qg0, qg1, qg2, pt);
       bool ml, mh;
-      const LSPoint nlo = tighten(lo, pt[0], pt[2], pt[1], ml);
-      const LSPoint nhi = tighten(hi, pt[1], pt[2], pt[0], mh);
-      if (!done) { lo = nlo; hi = nhi; swap = ml | mh; it++; }
+      lo = tighten(lo, pt[0], pt[2], pt[1], done, ml);
+      hi = tighten(hi, pt[1], pt[2], pt[0], done, mh);
+      // a finished env moves nothing, so swap turns false and keeps it finished (`done` is sticky through !swap); its count may run on
+      swap = ml | mh; it++;
     }
     PG_LTICK(s, 22);      // bracketing rounds
     {   // costs of the two points the bracket ended with
