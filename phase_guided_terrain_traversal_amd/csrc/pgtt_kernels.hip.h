@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
     slots.clear_all();
     __syncthreads();
   }
-  s.niter = 0; s.niter_max = 0;
+  s.niter = 0; s.niter_max = 0; s.pen_overflow = false;
   QPhysics ph(m, em, s, l);
   QSolver sol(m, s, slots);
   sol.lds_slots = HAS_TERRAIN && nbox > 0;
@@ -225,6 +225,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
       }
     }
     sol.solve();
+    const int pen_ovf = last ? quad_sum_i(sub_sum_i(s.pen_overflow ? 1 : 0)) : 0;      // over the lanes of the env, all lanes active
     if (last && lead) {
       float* __restrict__ Fr = a.buf.frame;
       int ee = e; asm volatile("" : "+v"(ee));
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
         for (int k = 0; k < 6; k++) v += accA[r][k] * s.qacc_b[k];
         Fr[(PGTT_F_ACCEL + r) * (long)N + ee] = v;
       }
-      if (a.buf.dbg_niter) a.buf.dbg_niter[ee] = s.niter_max;
+      if (a.buf.dbg_niter) a.buf.dbg_niter[ee] = s.niter_max | (pen_ovf > 0 ? PGTT_DBG_PEN_OVERFLOW : 0);
     }
     if (MODE == MODE_STEP) {
       // ---- semi-implicit Euler (eulerdamp disabled)

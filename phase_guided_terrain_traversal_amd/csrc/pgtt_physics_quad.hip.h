@@ -222,6 +222,7 @@ struct QSim {
   // outputs
   float qacc_b[6], qacc_l[3];
   int niter, niter_max;
+  bool pen_overflow;         // some substep of this call met more than kMaxPenQ simultaneously penetrating boxes under this foot (collide())
 };
 
 // y = A x
@@ -789,6 +790,26 @@ struct QPhysics {
       slots.at(at, 7) = pw.x; slots.at(at, 8) = pw.y; slots.at(at, 9) = pw.z;
       slots.at(at, 10) = nw.x; slots.at(at, 11) = nw.y; slots.at(at, 12) = nw.z;
     };
+    // MORE than kMaxPenQ boxes penetrated by one foot at once (never on the shipped / generated terrains - at most three boxes meet at a
+    // seam - but reachable through pgtt_set_terrain): MJX ranks all pairs by centre distance, cuts at max_geom_pairs and keeps the
+    // max_contact_points DEEPEST of the env, so a foot can never need more than its kMaxPenQ deepest pairs - unless the rank cut removes
+    // one of them.  The table therefore keeps the kMaxPenQ deepest pairs of the foot (a newcomer replaces the shallowest entry when it is
+    // deeper; equal depth: the entry stays) and the call raises PGTT_DBG_PEN_OVERFLOW in dbg_niter, because with replaced entries the
+    // table is no longer in scan order (the tie rule of the selection below) and the rank cut is not re-examined for the dropped pairs.
+    // `mine`: this lane computed the pair and parks its contact point / normal.  Only reached through the wave-uniform test below.
+    auto keep_deepest = [&](const QPen& g, bool mine, V3 pw, V3 nw) {
+      const bool pen_new = g.dist < 0.f, room = npen < kMaxPenQ;
+      int imax = 0; float dmax = pen[0].dist;
+#pragma unroll
+      for (int i = 1; i < kMaxPenQ; i++) { const bool later = pen[i].dist >= dmax; dmax = later ? pen[i].dist : dmax; imax = later ? i : imax; }
+      const bool put = pen_new & (room | (g.dist < dmax));
+      const int at = room ? npen : imax;
+#pragma unroll
+      for (int i = 0; i < kMaxPenQ; i++) { const bool hit = put & (i == at); pen[i].dist = hit ? g.dist : pen[i].dist; pen[i].key = hit ? g.key : pen[i].key; pen[i].idx = hit ? g.idx : pen[i].idx; }
+      npen += (pen_new & room) ? 1 : 0;
+      if (put & mine) park(at, pw, nw);
+      s.pen_overflow |= pen_new & !room;
+    };
     for (;;) {
       if (__ballot((cm[0] | cm[1] | cm[2] | cm[3]) != 0u) == 0ull) break;
       int b;
@@ -812,11 +833,16 @@ struct QPhysics {
       sphere_box(s.footc, rad, tb, nd, pw, nw);
       QPen pp; pp.dist = have ? nd : 1.f; pp.key = norm(v3(tb.px, tb.py, tb.pz) - s.footc) - keyC; pp.idx = l * nbox + (have ? b : 0);
       if (kSubs == 1) {
+        if (__builtin_expect(__ballot((pp.dist < 0.f) & (npen >= kMaxPenQ)) != 0ull, 0)) { keep_deepest(pp, true, pw, nw); continue; }
         if ((pp.dist < 0.f) & (npen < kMaxPenQ)) park(npen, pw, nw);
         keep(pp);
       } else if (kSubs == 2) {
         QPen g0{sub_bcast<0>(pp.dist), sub_bcast<0>(pp.key), sub_bcast<0>(pp.idx)}, g1{sub_bcast<1>(pp.dist), sub_bcast<1>(pp.key), sub_bcast<1>(pp.idx)};
         const int before = ((threadIdx.x & 1) && g0.dist < 0.f) ? 1 : 0;
+        if (__builtin_expect(__ballot(npen + (g0.dist < 0.f ? 1 : 0) + (g1.dist < 0.f ? 1 : 0) > kMaxPenQ) != 0ull, 0)) {
+          keep_deepest(g0, (threadIdx.x & 1) == 0, pw, nw); keep_deepest(g1, (threadIdx.x & 1) == 1, pw, nw);
+          continue;
+        }
         if ((pp.dist < 0.f) & (npen + before < kMaxPenQ)) park(npen + before, pw, nw);
         keep(g0); keep(g1);
       } else {
@@ -825,6 +851,10 @@ struct QPhysics {
         QPen g0{sub_bcast<0>(pp.dist), sub_bcast<0>(pp.key), sub_bcast<0>(pp.idx)}, g1{sub_bcast<1>(pp.dist), sub_bcast<1>(pp.key), sub_bcast<1>(pp.idx)};
         QPen g2{sub_bcast<2>(pp.dist), sub_bcast<2>(pp.key), sub_bcast<2>(pp.idx)}, g3{sub_bcast<3>(pp.dist), sub_bcast<3>(pp.key), sub_bcast<3>(pp.idx)};
         const int f0 = g0.dist < 0.f ? 1 : 0, f1 = g1.dist < 0.f ? 1 : 0, f2 = g2.dist < 0.f ? 1 : 0;
+        if (__builtin_expect(__ballot(npen + f0 + f1 + f2 + (g3.dist < 0.f ? 1 : 0) > kMaxPenQ) != 0ull, 0)) {
+          keep_deepest(g0, r == 0, pw, nw); keep_deepest(g1, r == 1, pw, nw); keep_deepest(g2, r == 2, pw, nw); keep_deepest(g3, r == 3, pw, nw);
+          continue;
+        }
         const bool h0 = (r & 1) != 0, h1 = (r & 2) != 0;
         const int before = h1 ? (h0 ? f0 + f1 + f2 : f0 + f1) : (h0 ? f0 : 0);        // penetrating pairs of the lower sub-lanes
         if ((pp.dist < 0.f) & (npen + before < kMaxPenQ)) park(npen + before, pw, nw);
@@ -1439,7 +1469,7 @@ struct QSolver {
       // zeros and add exact zeros) - a not-taken branch costs a one-wave SIMD ~10 cycles, and a round has a dozen instructions per pair
       if (kTerrainTU || any_lim || any_con0) ls_row2d<NA, COST>(hx_ja, hx_jv, hx_D, al, q);       // own (limit row, plane row), picked once per search
       if (kTerrainTU || nslots > 0) ls_row2d<NA, COST>(ls_ja[0], ls_jv[0], ls_D[0], al, q);
-      if (nslots > 2) ls_row2d<NA, COST>(ls_ja[1], ls_jv[1], ls_D[1], al, q);
+      if (__builtin_expect(nslots > 2, 0)) ls_row2d<NA, COST>(ls_ja[1], ls_jv[1], ls_D[1], al, q);      // three or four box contacts on one foot: rare, out of line
     }
 #pragma unroll
     for (int a = 0; a < NA; a++) {

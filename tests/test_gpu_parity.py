@@ -91,8 +91,16 @@ def per_env_errors(g, hb):
 # The residue are solves that converge exactly AT the cap in the oracle (gradient 0.6 -> 4e-7 in the fifth iteration) and one
 # line-search round later on the GPU; the bars below are the measured rates x 2 (binomial noise of a 10-15 k sample).
 W_FLOOR = {4: 0.72, 1: 0.81}                 # measured - 5 points
-VIOL_CAP = {4: dict(qpos=0.003, qvel=0.004, warm=0.008, info=0.003, hist=0.006, scan=0.002, obs=0.006, priv=0.008, frame=0.008, reward=0.003, metrics=0.006),
-            1: dict(qpos=0.0015, qvel=0.0015, warm=0.004, info=0.0015, hist=0.004, scan=0.002, obs=0.004, priv=0.005, frame=0.005, reward=0.0015, metrics=0.004)}
+VIOL_CAP = {4: dict(qpos=0.003, qvel=0.004, warm=0.008, info=0.003, hist=0.006, scan=0.002, obs=0.004, priv=0.005, frame=0.005, reward=0.003, metrics=0.006),
+            1: dict(qpos=0.0015, qvel=0.0015, warm=0.004, info=0.0015, hist=0.004, scan=0.002, obs=0.003, priv=0.004, frame=0.004, reward=0.0015, metrics=0.004)}
+# Round 3 (profiles/r03_parity_p90.txt): percentiles of the GPU-vs-oracle error next to the oracle's own fp32-vs-fp64 error.
+#   on W:        GPU p90 / oracle p90 = 1.26-1.47 (qpos 3 ulp vs 2 ulp of a unit coordinate), p99 1.2-1.45; observation / sensor-frame rows (relative):
+#                p99.9 = 1.8e-3 .. 4.4e-3  ->  tolerances below = 2 x that (they were 2e-2);
+#   all steps:   p90 ratio 1.8-2.0 - with the correctly rounded division / sqrt build (make PRECISE_DIV=1) just the same (1.8-2.2), and the ORACLE's two fp32
+#                builds against each other (portable vs -O3 -march=native, tools/cpu_fp32_pair_stats.py, no GPU involved) 1.7-2.1: on the env-steps whose
+#                solve is cut short two fp32 evaluations differ from each other by more than either differs from fp64.  Bounded at 2.6.
+P90_W_RATIO, P90_ALL_RATIO = 1.75, 2.6
+P90_FLOOR = dict(qpos=1.2e-7, qvel=5e-6, obs=2e-6, frame=3e-6)        # one rounding of the quantity's typical size
 
 
 def run_parity(task, n, terrain, steps, dr=False, autoreset=False, noise=1.0, method="pgtt", ctrl_dt=None, w_floor=None, cap_scale=1.0, med_tol=2e-6):
@@ -136,8 +144,9 @@ def run_parity(task, n, terrain, steps, dr=False, autoreset=False, noise=1.0, me
     nviol = {}
     well_total, well_flag_mismatch, well_set_mismatch, well_done_mismatch = 0, 0, 0, 0
     dt_ctrl = 0.005 * nsub
-    tols = (("qpos", 1e-4), ("qvel", 1e-4 / dt_ctrl), ("warm", 1e-2), ("info", 2e-4), ("hist", 2e-2), ("scan", 1e-5), ("obs", 2e-2), ("priv", 2e-2),
-            ("frame", 2e-2), ("reward", 2e-4), ("metrics", 2e-3))
+    tols = (("qpos", 1e-4), ("qvel", 1e-4 / dt_ctrl), ("warm", 1e-2), ("info", 2e-4), ("hist", 2e-2), ("scan", 1e-5), ("obs", 6e-3), ("priv", 1e-2),
+            ("frame", 1e-2), ("reward", 2e-4), ("metrics", 2e-3))
+    WELL = []
     for k in range(steps):
         sync_to_host(env, hb, h64)
         act = np.tanh(rng.normal(size=(n, 12)) * 0.6).astype(np.float32)
@@ -152,7 +161,7 @@ def run_parity(task, n, terrain, steps, dr=False, autoreset=False, noise=1.0, me
         EG.append(eg); EF.append(ef)
         # W: every solve of the step reached its minimiser in fp64, and the oracle's fp32 build lands on the same point
         well = (r64 < 1e-6) & (ef["qpos"] < 1e-5) & (ef["qvel"] < 1e-3)
-        well_total += int(well.sum())
+        well_total += int(well.sum()); WELL.append(well)
         # integers never depend on the solver path; nothing may blow up anywhere
         assert np.array_equal(g["istate"], hb["istate"]), k
         assert all(np.isfinite(g[kk]).all() for kk in ("state", "frame", "obs_state", "obs_priv", "reward", "metrics", "scan_z")), k
@@ -191,6 +200,16 @@ def run_parity(task, n, terrain, steps, dr=False, autoreset=False, noise=1.0, me
     assert stats["frac_gpu_1e4"] >= stats["frac_fp_1e4"] - slack
     if steps * n >= 2000:
         assert stats["p99_gpu"] <= 2.5 * stats["p99_fp"] + 1e-4
+        # 90th percentiles: on W within 1.75 x the oracle's own fp32 noise (measured 1.26-1.47), on all env-steps within 2.6 x (see the table above)
+        Wm = np.concatenate(WELL)
+        for key in ("qpos", "qvel", "obs", "frame"):
+            gq, fq = cat(EG, key), cat(EF, key)
+            pw_g, pw_f = np.percentile(gq[Wm], 90), np.percentile(fq[Wm], 90)
+            pa_g, pa_f = np.percentile(gq, 90), np.percentile(fq, 90)
+            stats[f"p90_{key}"] = (float(pw_g), float(pw_f), float(pa_g), float(pa_f))
+            assert pw_g <= P90_W_RATIO * pw_f + P90_FLOOR[key], (key, "W", pw_g, pw_f)
+            assert pa_g <= P90_ALL_RATIO * pa_f + 20 * P90_FLOOR[key], (key, "all", pa_g, pa_f)
+        print("p90 (GPU on W, oracle fp32-vs-fp64 on W, GPU all, oracle all):", {k: tuple(f"{x:.2e}" for x in v) for k, v in stats.items() if k.startswith("p90_")})
     env.close()
     return stats
 
@@ -337,3 +356,62 @@ def test_equal_depth_tie_break_parity(layout):
     st = run_parity("stairs", 128, overlap_terrain(), steps=25, w_floor=0.48, cap_scale=4.0, med_tol=6e-6)      # up to 12 simultaneous contacts: W = 55 % here, stiffer solves
     assert st["box_contacts"] > 2000
     assert st["well_set_mismatch"] <= 2
+
+
+def stacked_slabs_terrain():
+    """MORE than four boxes penetrated by one foot (kMaxPenQ): ten slabs of graded height, tops 1.5 mm apart, overlap over the
+    whole spawn area.  A standing foot is 5-15 mm inside the tallest one and so penetrates six to ten slabs at once, every env has 25-40
+    penetrating pairs for 4 contact slots and MJX's max_geom_pairs = 25 cut (go2_mjx_feetonly.xml:14-15) bites as well.  MJX keeps the four
+    DEEPEST pairs of the env among the 25 closest ones."""
+    T = []
+    for v in range(4):
+        rows = [[0.05 * k - 0.2 + 0.03 * v, 0.04 * k - 0.15, 0.5 * (0.040 - 0.0015 * k), 1, 0, 0, 0, 3.0, 3.0, 0.5 * (0.040 - 0.0015 * k)] for k in range(10)]
+        rows += [[100.0 + k, 100.0 + k, 100.0 + k, 1, 0, 0, 0, 0.5, 0.5, 0.5] for k in range(90)]
+        T.append(rows)
+    return np.asarray(T, dtype=np.float32)
+
+
+def test_more_penetrating_boxes_than_tracked_per_foot():
+    """kMaxPenQ overflow is REPORTED, not silent.  The per-foot candidate table of the kernels holds 4 penetrating pairs (enough for every shipped /
+    generated terrain: at most three boxes meet at a seam); with more it keeps the foot's 4 deepest and raises PGTT_DBG_PEN_OVERFLOW in dbg_niter.
+    MJX's answer in that regime also depends on the max_geom_pairs rank cut over ALL 40 pairs (a deep pair whose box centre is far away is
+    cut and a shallower one takes its slot), which the 4-entry table cannot follow - so here: every env-step with a mismatching ACTIVE set
+    must carry the flag, env-steps WITHOUT the flag match the oracle exactly on W, nothing blows up, integers stay exact."""
+    terrain = stacked_slabs_terrain()
+    n = 128
+    for lay in ("hex", "oct", "quad"):
+        EXEC["layout"] = lay
+        try:
+            env, hb, cs, ms = make_pair("stairs", n, terrain)
+            h64 = oracle.HostBuffers(n, with_variant=True); h64["variant"][...] = hb["variant"]
+            env.reset(3); oracle.reset(cs, ms, terrain, hb, seed=3, nthreads=8)
+            rng = np.random.default_rng(1)
+            well_total = mism_flagged = mism_unflagged = flagged = total = deep_pairs = 0
+            for k in range(12):
+                sync_to_host(env, hb, h64)
+                act = np.tanh(rng.normal(size=(n, 12)) * 0.3).astype(np.float32)
+                env.step(torch.from_numpy(act).cuda())
+                r64 = np.zeros(n)
+                oracle.step(cs, ms, terrain, hb, act, seed=3, nthreads=8)
+                oracle.step(cs, ms, terrain, h64, act, seed=3, nthreads=8, fp64=True, resid=r64)
+                torch.cuda.synchronize()
+                g = {kk: v.cpu().numpy() for kk, v in env.buffers.items()}
+                assert all(np.isfinite(g[kk]).all() for kk in ("state", "frame", "obs_state", "obs_priv", "reward", "metrics"))
+                assert np.array_equal(g["istate"], hb["istate"])
+                assert np.abs(g["state"][:19] - hb["state"][:19]).max() < 0.5
+                ef = per_env_errors(hb.arrays, h64)
+                well = (r64 < 1e-6) & (ef["qpos"] < 1e-5) & (ef["qvel"] < 1e-3)
+                ga, ha = active_sets(g["dbg_contact"], g["dbg_dist"]), active_sets(hb["dbg_contact"], hb["dbg_dist"])
+                sm = np.array([a != b for a, b in zip(ga, ha)])
+                fl = (g["dbg_niter"] & 0x10000) != 0
+                assert ((g["dbg_niter"] & 0xFFFF) <= 5).all()
+                mism_flagged += int((sm & well & fl).sum()); mism_unflagged += int((sm & well & ~fl).sum()); well_total += int(well.sum())
+                flagged += int(fl.sum()); total += n
+                deep_pairs += sum(1 for a in ha for (_, b) in a if b >= 0)
+            print(lay, "env-steps", total, "flagged", flagged, "| in W", well_total, ": ACTIVE-set mismatches with the flag", mism_flagged, ", without", mism_unflagged, "| oracle box contacts", deep_pairs)
+            assert flagged > 0.5 * total, (lay, flagged, total)                     # the overflow is reported (feet in the air do not overflow)
+            assert deep_pairs > 3 * total                                            # the oracle keeps (nearly) four box contacts per env here
+            assert well_total > 0.3 * total and mism_unflagged <= 1, (lay, mism_unflagged, well_total)
+            env.close()
+        finally:
+            EXEC["layout"] = None

@@ -68,6 +68,25 @@ def summarise(name, eg, ef, ni, fm, sm, rs):
         print("   ", key, "gpu|all  ", out[f"gpu_{key}_all"], " fp|all", out[f"fp_{key}_all"])
     return out
 
+def ratios(lay="hex"):
+    """p50 / p90 / p99 of the GPU-vs-oracle error next to the oracle's own fp32-vs-fp64 error, all env-steps and W, for whichever build PGTT_LIB names:
+    the column of profiles/r03_parity_p90.txt (product, and `make PRECISE_DIV=1`)"""
+    from phase_guided_terrain_traversal_amd import native
+    A = os.path.join(ROOT, "phase_guided_terrain_traversal_amd", "assets", "terrains")
+    P.EXEC["layout"] = lay
+    print("build:", os.path.basename(native.LIB_PATH), "layout", lay)
+    for name, args in (("flat", ("flat_terrain", 512, None, 60)), ("level4", ("stairs", 512, np.load(os.path.join(A, "level4.npy")), 60))):
+        eg, ef, ni, fm, sm, rs = collect(*args)
+        W = (rs[1] < 1e-6) & (ef["qpos"] < 1e-5) & (ef["qvel"] < 1e-3)
+        for key in ("qpos", "qvel", "obs", "frame"):
+            for tag, f in (("all", np.ones_like(W)), ("W", W)):
+                g, o = np.percentile(eg[key][f], [50, 90, 99, 99.9]), np.percentile(ef[key][f], [50, 90, 99, 99.9])
+                print(f"  {name:7s} {key:5s} {tag:3s} gpu p50/p90/p99/p99.9 {g[0]:.2e} {g[1]:.2e} {g[2]:.2e} {g[3]:.2e} | oracle f32-vs-f64 {o[0]:.2e} {o[1]:.2e} {o[2]:.2e} {o[3]:.2e} | ratio p50 {g[0] / max(o[0], 1e-30):.2f} p90 {g[1] / max(o[1], 1e-30):.2f} p99 {g[2] / max(o[2], 1e-30):.2f}")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--ratios":
+    ratios(sys.argv[2] if len(sys.argv) > 2 else "hex")
+    sys.exit(0)
 if __name__ == "__main__":
     A = os.path.join(ROOT, "phase_guided_terrain_traversal_amd", "assets", "terrains")
     res = {}
