@@ -68,6 +68,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample-steps", type=int, default=100)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU test hook with a stub env (not a result)")
     ap.add_argument("--layout", default="auto", choices=["auto", "quad", "oct", "hex"], help="lane layout of physics_kernel (PgttConfig.lane_layout)")
+    ap.add_argument("--unsorted-variants", action="store_true", help="level workloads: keep the terrain variants in draw order instead of labelling envs by variant")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other single-GPU configs after the headline window")
     ap.add_argument("--other-steps", type=int, default=20)
     return ap.parse_args(argv)
@@ -127,6 +128,11 @@ def build_env(args, rank, world, local):
         level = "level4" if args.workload == "level4" else "level%d" % CURRICULUM[(rank if args.stage is None else args.stage) % len(CURRICULUM)]
         terrain = np.load(os.path.join(assets, level + ".npy"))
         variant = np.random.Generator(np.random.Philox(key=[2, 0])).integers(0, terrain.shape[0], n * max(world, 1))[off:off + n]
+        # envs are LABELLED in the order of their terrain variant (same multiset of draws): neighbouring envs then share a variant,
+        # and since physics_kernel hands every XCD a contiguous range of envs each XCD's L2 reads ~1/8 of the terrain table per launch instead of
+        # all of it (profiles/hbm_traffic.json: 13.9 -> see there MB fetched per launch); --unsorted-variants keeps the draw order
+        if not args.unsorted_variants:
+            variant = np.sort(variant)
         kw["variant"] = torch.from_numpy(variant.astype(np.int32))
     else:
         if args.workload == "wfc_dr":           # BASELINE configs[3]: WFC-generated terrain (host, once) + full randomize.py DR
@@ -372,7 +378,8 @@ def cpu_baseline(args, cfg, terrain, task, n):
     cs, ms = abi.config_struct(cfg2), abi.model_struct(mjcf.load_model(task))
     hb = oracle.HostBuffers(n, with_variant=terrain is not None, debug=False)
     if terrain is not None:
-        hb["variant"][:] = np.random.Generator(np.random.Philox(key=[2, 0])).integers(0, terrain.shape[0], n).astype(np.int32)
+        v = np.random.Generator(np.random.Philox(key=[2, 0])).integers(0, terrain.shape[0], n).astype(np.int32)
+        hb["variant"][:] = v if args.unsorted_variants else np.sort(v)
     oracle.reset(cs, ms, terrain, hb, seed=0, nthreads=cores)
     rng = np.random.default_rng(1)
     acts = [np.tanh(rng.normal(size=(n, 12)) * 0.6).astype(np.float32) for _ in range(8)]

@@ -163,9 +163,10 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
     PG_TICK(s, 1);
     ph.constraint_stage(HAS_TERRAIN && boxes != nullptr && nbox > 0, a.buf.box_friction, N, e, slots);
     PG_TICK(s, 2);
-    // ---- sensors of the last forward (pre-integration state), written BEFORE the solve; the accelerometer is
-    //      kept as an affine map of qacc[0:6]
-    float accA[3][6], acc0[3];
+    // ---- sensors of the last forward (pre-integration state), written BEFORE the solve; the accelerometer is an affine map of
+    //      qacc[0:6]: its constant part is kept across the solve (3 values), the 3 x 6 matrix is formed after it from frames that are
+    //      still live (R0, cdr, imu, com) - 18 registers less across the Newton loop of a kernel that spills to scratch
+    float acc0[3];
     const bool last = sub == nsub - 1;
     if (last) {
       float* __restrict__ Fr = a.buf.frame;
@@ -180,13 +181,6 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
       for (int k = 0; k < 3; k++) cacc = cacc + s.cddr[k] * s.vb[3 + k];
       V3 a0 = mtmul(s.R0, cacc.l - cross(dif, cacc.a)) + cross(gyro, llin);
       acc0[0] = a0.x; acc0[1] = a0.y; acc0[2] = a0.z;
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        V3 ct = mtmul(s.R0, v3(k == 0, k == 1, k == 2));
-        V3 cr = mtmul(s.R0, s.cdr[k].l - cross(dif, s.cdr[k].a));
-        accA[0][k] = ct.x; accA[1][k] = ct.y; accA[2][k] = ct.z;
-        accA[0][3 + k] = cr.x; accA[1][3 + k] = cr.y; accA[2][3 + k] = cr.z;
-      }
       auto put3 = [&](int row, V3 v) { Fr[row * (long)N + ee] = v.x; Fr[(row + 1) * (long)N + ee] = v.y; Fr[(row + 2) * (long)N + ee] = v.z; };
       if (lead) {
         put3(PGTT_F_GYRO, gyro); put3(PGTT_F_GLOBAL_LINVEL, glin); put3(PGTT_F_GLOBAL_ANGVEL, w); put3(PGTT_F_LOCAL_LINVEL, llin);
@@ -229,6 +223,15 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
     if (last && lead) {
       float* __restrict__ Fr = a.buf.frame;
       int ee = e; asm volatile("" : "+v"(ee));
+      float accA[3][6];
+      const V3 dif = s.imu - s.com;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        V3 ct = mtmul(s.R0, v3(k == 0, k == 1, k == 2));
+        V3 cr = mtmul(s.R0, s.cdr[k].l - cross(dif, s.cdr[k].a));
+        accA[0][k] = ct.x; accA[1][k] = ct.y; accA[2][k] = ct.z;
+        accA[0][3 + k] = cr.x; accA[1][3 + k] = cr.y; accA[2][3 + k] = cr.z;
+      }
 #pragma unroll
       for (int r = 0; r < 3; r++) {
         float v = acc0[r];

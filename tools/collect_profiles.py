@@ -16,23 +16,42 @@ hdr = (f"# rocprofv3 PMC summary, {tag}: {note}; 4096 envs on level4, per-launch
        "# FETCH_SIZE / WRITE_SIZE in KB as reported; summarised by tools/pmc_summary.py\n")
 body = open(os.path.join(src, "pmc_summary.txt")).read()
 open(os.path.join(dst, f"{tag}_level4_pmc_summary.txt"), "w").write(hdr + body)
-val = {}
-for ln in body.splitlines():
-    m = re.match(r"void pgtt::physics_kernel<0.*?\s(FETCH_SIZE|WRITE_SIZE)\s+launches=\s*\d+ mean=([\d.e+]+)", ln)
-    if m:
-        val[m.group(1)] = float(m.group(2)) * 1024
-tp = os.path.join(dst, "hbm_traffic.json")
-t = json.load(open(tp))
+FETCH_CORR, WRITE_CORR = 2.0, 1.0
 # gfx950 correction (MI355X_MICROARCH.md "HBM"; calibrated on this library's own access pattern with tools/probes/traffic_calib.hip -
 # 4-byte-per-lane coalesced SoA rows, 256 MiB read and written: FETCH_SIZE reports exactly 1/2 of the bytes read, WRITE_SIZE is exact)
-FETCH_CORR, WRITE_CORR = 2.0, 1.0
-t["level4_4096"] = {"physics_bytes_per_launch": FETCH_CORR * val["FETCH_SIZE"] + WRITE_CORR * val["WRITE_SIZE"],
-                    "fetch_bytes": FETCH_CORR * val["FETCH_SIZE"], "write_bytes": WRITE_CORR * val["WRITE_SIZE"],
-                    "raw_counters_KB": {"FETCH_SIZE": val["FETCH_SIZE"] / 1024, "WRITE_SIZE": val["WRITE_SIZE"] / 1024},
-                    "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/{tag}_level4_pmc_summary.txt), KB * 1024, FETCH x 2 (gfx950 correction, "
-                            "calibrated with tools/probes/traffic_calib.hip: 131 082 KB reported for 262 144 KB read, WRITE exact). These are L2 <-> fabric requests and include "
-                            "Infinity-Cache hits: the 8 XCD L2s are not coherent with each other and start every launch cold, so each launch re-reads its state rows (1x) AND "
-                            "the 0.8 MB terrain table once per XCD (6.4 MB, the one-forward reset launch shows the same fixed 8 MB) from the Infinity Cache; writes are "
-                            "16-byte pieces of 128-byte lines per wave (4 envs per wave in the hex layout), counted as 64-byte requests"}
+NOTE = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes (profiles/%s_%s), KB * 1024, FETCH x 2 (gfx950 correction, calibrated with "
+        "tools/probes/traffic_calib.hip: 131 082 KB reported for 262 144 KB read, WRITE exact).  L2 <-> fabric requests incl. Infinity-Cache hits: the 8 XCD L2s "
+        "are not coherent with each other, so each launch reads its state rows (1x) and, per XCD, the records of the terrain variants its envs stand on "
+        "(bench.py labels envs in variant order: ~1/8 of the 0.8 MB table per XCD; in draw order every XCD reads all of it); writes are 16-byte pieces of "
+        "64-byte requests per wave (4 envs per wave in the hex layout, 8 in oct).  valu_busy = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES.")
+tp = os.path.join(dst, "hbm_traffic.json")
+t = json.load(open(tp))
+
+
+def entry(text, fname):
+    val = {}
+    for ln in text.splitlines():
+        m = re.match(r"void pgtt::physics_kernel<0.*?\s(\w+)\s+launches=\s*\d+ mean=([\d.e+]+)", ln)
+        if m:
+            val[m.group(1)] = float(m.group(2))
+    e = {"physics_bytes_per_launch": FETCH_CORR * val["FETCH_SIZE"] * 1024 + WRITE_CORR * val["WRITE_SIZE"] * 1024,
+         "fetch_bytes": FETCH_CORR * val["FETCH_SIZE"] * 1024, "write_bytes": WRITE_CORR * val["WRITE_SIZE"] * 1024,
+         "raw_counters_KB": {"FETCH_SIZE": val["FETCH_SIZE"], "WRITE_SIZE": val["WRITE_SIZE"]}, "note": NOTE % (tag, fname)}
+    if "SQ_ACTIVE_INST_VALU" in val and "SQ_WAVE_CYCLES" in val:
+        e["valu_busy"] = val["SQ_ACTIVE_INST_VALU"] / val["SQ_WAVE_CYCLES"]
+        e["wait_any"] = val.get("SQ_WAIT_ANY", 0.0) / val["SQ_WAVE_CYCLES"]
+        e["valu_insts_per_launch"] = val.get("SQ_INSTS_VALU"); e["waves"] = val.get("SQ_WAVES")
+    if "SQ_INSTS_VALU_MFMA_MOPS_F32" in val:
+        e["mfma_ops"] = val["SQ_INSTS_VALU_MFMA_MOPS_F32"]
+    return e
+
+
+t["level4_4096"] = entry(body, "level4_pmc_summary.txt")
+for T, key in (("flat", "flat_4096"), ("wfc_dr_8192", "wfc_dr_8192"), ("level4_unsorted", "level4_4096_unsorted_variants")):
+    f = os.path.join(src, f"pmc_summary_{T}.txt")
+    if os.path.exists(f):
+        txt = open(f).read()
+        open(os.path.join(dst, f"{tag}_{T}_pmc_summary.txt"), "w").write(hdr.replace("4096 envs on level4", T) + txt)
+        t[key] = entry(txt, f"{T}_pmc_summary.txt")
 json.dump(t, open(tp, "w"), indent=1)
-print("collected", tag, t["level4_4096"]["physics_bytes_per_launch"])
+print("collected", tag, {k: (round(v["physics_bytes_per_launch"] / 1e6, 2), round(v.get("valu_busy", 0), 3)) for k, v in t.items()})

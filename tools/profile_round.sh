@@ -16,6 +16,13 @@ for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c -d $O/pmc_$c -o p --output
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU -d $O/pmc_sq -o p --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -o p --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > /dev/null 2>&1
 python tools/pmc_summary.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_sq $O/pmc_mfma > $O/pmc_summary.txt
+# the same counters for the other single-GPU configs (BASELINE configs[1], configs[3]) and for level4 with the variants in draw order
+for W in "flat:--workload flat" "wfc_dr_8192:--workload wfc_dr --envs 8192" "level4_unsorted:--unsorted-variants"; do
+  T=${W%%:*}; A=${W#*:}
+  for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c -d $O/pmc_${T}_$c -o p --output-format csv -- python bench.py $A --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > /dev/null 2>&1; done
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 -d $O/pmc_${T}_sq -o p --output-format csv -- python bench.py $A --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > /dev/null 2>&1
+  python tools/pmc_summary.py $O/pmc_${T}_FETCH_SIZE $O/pmc_${T}_WRITE_SIZE $O/pmc_${T}_sq > $O/pmc_summary_$T.txt
+done
 cp $O/kt/*kernel_stats.csv $O/kernel_stats.csv
 for f in $O/bench_*.json $O/driver_cmd_bench.json $O/kt_bench.json; do python -c "import sys,json; d=json.load(open('$f')); print('$f', d['value'], d['ms_per_step'], d['kernels_ms'], d.get('wall_over_kernels'))"; done
 grep "physics_kernel<0" $O/pmc_summary.txt | grep -E "FETCH|WRITE|WAVE_CYCLES|WAIT_ANY|ACTIVE_INST_VALU|INSTS_|SQ_WAVES"
