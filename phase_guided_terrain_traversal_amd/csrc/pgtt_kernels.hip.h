@@ -408,6 +408,13 @@ PG_INL float gait_get_z(float phi, float swing_height, float swing_min) {
   return cubic_hermite((phi - T_peak) / T_swing, swing_height, swing_min, T_swing * 0.f, T_swing * 0.f);
 }
 
+// fmodf(x, y) for 0 <= x < 2 y - the phase clock: phase in [0, 2 pi) plus an increment below 2 pi.  There fmod is x or x - y, and x - y is exact
+// (Sterbenz: y <= x <= 2 y), so the select returns fmodf's bits at 3 instructions instead of ~32 per foot; anything else takes the library call
+PG_INL float fmod_once(float x, float y) {
+  if (__builtin_expect(__ballot(!((x >= 0.f) & (x < 2.0f * y))) != 0ull, 0)) return fmodf(x, y);
+  return x >= y ? x - y : x;
+}
+
 // Rewards, termination and bookkeeping of one control step (joystick_pgtt.py:193-227 / joystick.py): shared by the fused
 // observe kernel (sh_* in LDS) and by task_kernel (sh_* = per-lane arrays, all indices compile-time constants).
 struct TaskScalars {
@@ -525,7 +532,7 @@ PG_INL void task_rewards(const float* sh_st, const float* sh_fr, const float* sh
     // bookkeeping (joystick_pgtt.py:205-227)
     step_ctr += 1;
 #pragma unroll
-    for (int f = 0; f < 4; f++) phase[f] = fmodf(phase[f] + phase_dt, (float)(2 * M_PI));
+    for (int f = 0; f < 4; f++) phase[f] = fmod_once(phase[f] + phase_dt, (float)(2 * M_PI));
     timer -= 1;
     if (timer <= 0) {
 #pragma unroll
@@ -811,8 +818,10 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
     else if (i < 6) { base = sh_fr[PGTT_F_GRAVITY + i - 3]; rblk = 1; sidx = i - 3; scale = cfg->noise_gravity; }
     else if (i < 18) { base = sh_st[PGTT_S_QPOS + 7 + i - 6]; rblk = 2; sidx = i - 6; scale = cfg->noise_joint_pos; offs = m->key_qpos[7 + i - 6]; }
     else if (i < 30) { base = sh_st[PGTT_S_QVEL + 6 + i - 18]; rblk = 5; sidx = i - 18; scale = cfg->noise_joint_vel; }
-    else if (i < 34) base = cosf(sel4(i - 30, phase[0], phase[1], phase[2], phase[3]));
-    else if (i < 38) base = sinf(sel4(i - 34, phase[0], phase[1], phase[2], phase[3]));
+    else if (i < 38) {       // rows 30..33 cos(phase), 34..37 sin(phase): ONE sincos evaluation for the eight lanes instead of a cosf and a sinf expansion
+      float sn, cs; sincosf(sel4((i - 30) & 3, phase[0], phase[1], phase[2], phase[3]), &sn, &cs);
+      base = i < 34 ? cs : sn;
+    }
     else if (i < 38 + PGTT_NSCAN) { base = sh_scan[i - 38] - zmin; rblk = 8; sidx = i - 38; scale = cfg->noise_heightscan; }
     else if (i == 38 + PGTT_NSCAN) base = gait_freq;
     else if (i < 39 + PGTT_NSCAN + 12) base = sh_st[PGTT_S_LAST_ACT + i - (39 + PGTT_NSCAN)];
