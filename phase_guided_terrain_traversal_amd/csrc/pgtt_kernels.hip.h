@@ -361,6 +361,10 @@ PG_INL float wave_min(float v) {
 // direction in the box frame lv = -R[2][:] is the same for every ray of a box: its reciprocals are formed once per box
 // (v_rcp_f32, 1 ulp) and the six face parameters are (side - lp) * (1 / lv) instead of six divisions per ray; an
 // axis-parallel component gives 1 / (+-0) = +-inf and the same +-inf / NaN face parameters as the division.
+PG_INL float mul_unfused(float x, float y) {
+#pragma clang fp contract(off)
+  return x * y;
+}
 struct RayBox { float il[3]; bool upright; };
 PG_INL RayBox ray_box_prepare(const TerrainBox& tb) {
   // upright: the box z axis is along the world z axis (every shipped / generated terrain: boxes are only turned about z).  The ray
@@ -681,6 +685,23 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
       tb.hx = r[4].x; tb.hy = r[4].y; tb.hz = r[4].z; tb.pad = r[4].w;
       RayBox rb = ray_box_prepare(tb);
       rb.upright = __builtin_amdgcn_readfirstlane((int)rb.upright) != 0;      // the record is the same in every lane: keep the branch scalar
+      if (rb.upright && __builtin_amdgcn_readfirstlane((int)(tb.m02 == 0.f && tb.m12 == 0.f)) != 0) {
+        // a box turned about z only (m02 = m12 = 0 exactly): lp2 = 0 * relx + 0 * rely + m22 * relz = round(m22 * relz), and relz = oz - pz is the
+        // same for every ray of the env - the two z-face parameters and their validity are properties of the BOX; a ray only decides "inside the
+        // footprint or not".  Same values as ray_box_down's two-face form, ~20 instructions per box and ray pair less
+        const float lp2 = mul_unfused(tb.m22, oz - tb.pz);      // a product on its own (the generic form adds it to two exact zeros): must not be fused into sz - lp2
+        const float xt = (tb.sz - lp2) * rb.il[2], xb = (-tb.sz - lp2) * rb.il[2];
+        float hz = xt >= 0.f ? xt : INFINITY;
+        hz = ((xb >= 0.f) & (xb < hz)) ? xb : hz;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const V3 rel = org[k] - v3(tb.px, tb.py, tb.pz);
+          const float lp0 = tb.m00 * rel.x + tb.m10 * rel.y, lp1 = tb.m01 * rel.x + tb.m11 * rel.y;      // + m20 * relz = + (+-0): only the sign of a zero, and |lp| is what is tested
+          const bool inside = (fabsf(lp0) <= tb.sx) & (fabsf(lp1) <= tb.sy);
+          hit[k] = fminf(hit[k], inside ? hz : INFINITY);
+        }
+        return;
+      }
 #pragma unroll
       for (int k = 0; k < 2; k++) hit[k] = fminf(hit[k], ray_box_down(tb, rb, org[k]));
     };

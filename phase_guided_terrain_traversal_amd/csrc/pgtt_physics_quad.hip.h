@@ -1621,7 +1621,7 @@ struct QSolver {
     PG_LTICK(s, 20);      // set-up: M s, J s, row hand-over, Gauss coefficients
     LSPoint p0, lo0;
     { const float a0 = 0.f; ls_points<1>(&a0, jv_lim, jv0, qg0, qg1, qg2, &p0); }
-    { const float a1 = p0.alpha - div_normal(p0.d0, p0.d1); ls_points<1>(&a1, jv_lim, jv0, qg0, qg1, qg2, &lo0); }
+    { const float a1 = p0.alpha - div_normal(p0.d0, p0.d1); ls_points<1, false>(&a1, jv_lim, jv0, qg0, qg1, qg2, &lo0); }
     bool lesser = lo0.d0 < p0.d0;
     LSPoint hi = lesser ? p0 : lo0, lo = lesser ? lo0 : p0;
     bool swap = true; int it = 0;
