@@ -640,12 +640,12 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
     // that do not overlap the rectangle changes no hit).  min() over the hits does not depend on the visiting order.
     const float hx = 0.5f * (PGTT_SCAN_H - 1) * fabsf(cfg->scan_dist_x) + 1e-3f, hy = 0.5f * (PGTT_SCAN_W - 1) * fabsf(cfg->scan_dist_y) + 1e-3f;
     const float acy = fabsf(cy), asy = fabsf(sy);
-    // The survivors' records are COMPACTED into LDS (slot = number of surviving boxes before this one) and the ray loop reads them from
-    // there through wave-uniform addresses, the next record requested while the current one is tested: no scalar-memory round trip
-    // per box any more (a wave used to wait ~0.3 us for every 80-byte record; the slowest waves of a launch are those that stand among
-    // many boxes).  kScanSlots survivors fit; further ones (never on the shipped terrains) are read from the table as before.
+    // The survivors are COMPACTED into LDS (slot = number of surviving boxes before this one), prepared by the lane that owns them, and the ray
+    // loop reads them from there through wave-uniform addresses, the next one requested while the current one is tested: no scalar-memory
+    // round trip and no per-box arithmetic in the loop (a wave used to wait ~0.3 us for every 80-byte record; the slowest waves of a launch
+    // are those that stand among many boxes).  kScanSlots survivors fit; further ones (never on the shipped terrains) are read from the table.
     constexpr int kScanSlots = 40;
-    __shared__ float4 sh_box[kScanSlots * 5];
+    __shared__ float4 sh_box[kScanSlots * 3];
     unsigned long long todo[2];
     int nsurv = 0;
 #pragma unroll
@@ -661,9 +661,23 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
       const unsigned long long mk = __ballot(reach);
       const int slot = nsurv + __popcll(mk & ((1ull << lane) - 1ull));
       if (reach && slot < kScanSlots) {
-        sh_box[slot * 5 + 0] = brec[h][0]; sh_box[slot * 5 + 4] = brec[h][1];
-#pragma unroll
-        for (int q = 1; q < 4; q++) sh_box[slot * 5 + q] = reinterpret_cast<const float4*>(boxes + b)[q];
+        // The lane that owns a surviving box prepares it for the ray loop - all survivors at once, one per lane.  A box turned about z only
+        // (m20 = m21 = m02 = m12 = 0 exactly; every shipped / generated terrain) has lp2 = 0 * relx + 0 * rely + m22 * relz = round(m22 * relz)
+        // with relz = oz - pz the same for every ray of the env: the parameters of its two z faces and their validity are properties of the
+        // BOX (`hz` below, the value ray_box_down's two-face form returns for a ray inside the footprint); a ray only decides "inside or not".
+        // Such a box goes to LDS as the 9 numbers that test needs; any other box as its index (the loop reads its record from the table).
+        const float4 q0 = brec[h][0], q1 = reinterpret_cast<const float4*>(boxes + b)[1], q2 = reinterpret_cast<const float4*>(boxes + b)[2],
+                     q3 = reinterpret_cast<const float4*>(boxes + b)[3];
+        const float m22 = q3.w;
+        const bool fast = (q3.y == 0.f) & (q3.z == 0.f) & (m22 != 0.f) & (q2.y == 0.f) & (q3.x == 0.f);      // m20, m21, m22, m02, m12
+        const float il2 = __builtin_amdgcn_rcpf(-m22);
+        const float lp2 = mul_unfused(m22, oz - q0.z);       // a product on its own (the generic form adds it to two exact zeros): must not be fused into sz - lp2
+        const float xt = (q1.z - lp2) * il2, xb = (-q1.z - lp2) * il2;
+        float hz = xt >= 0.f ? xt : INFINITY;
+        hz = ((xb >= 0.f) & (xb < hz)) ? xb : hz;
+        sh_box[slot * 3 + 0] = make_float4(q0.x, q0.y, q1.w, q2.z);                    // px, py, m00, m10
+        sh_box[slot * 3 + 1] = make_float4(q2.x, q2.w, q1.x, q1.y);                    // m01, m11, sx, sy
+        sh_box[slot * 3 + 2] = make_float4(hz, fast ? 1.f : 0.f, __int_as_float(b), 0.f);
       }
       // boxes beyond the slots: the highest set bits of this half (slot order = bit order)
       int over = nsurv + __popcll(mk) - kScanSlots;
@@ -674,44 +688,34 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
     }
     __syncthreads();
     const int nslot = min(nsurv, kScanSlots);
-    auto load_slot = [&](int i, float4 (&r)[5]) {
+    auto load_slot = [&](int i, float4 (&r)[3]) {
 #pragma unroll
-      for (int q = 0; q < 5; q++) r[q] = sh_box[i * 5 + q];
+      for (int q = 0; q < 3; q++) r[q] = sh_box[i * 3 + q];
     };
-    auto test_box = [&](const float4 (&r)[5]) {
-      TerrainBox tb;
-      tb.px = r[0].x; tb.py = r[0].y; tb.pz = r[0].z; tb.rb = r[0].w; tb.sx = r[1].x; tb.sy = r[1].y; tb.sz = r[1].z; tb.m00 = r[1].w;
-      tb.m01 = r[2].x; tb.m02 = r[2].y; tb.m10 = r[2].z; tb.m11 = r[2].w; tb.m12 = r[3].x; tb.m20 = r[3].y; tb.m21 = r[3].z; tb.m22 = r[3].w;
-      tb.hx = r[4].x; tb.hy = r[4].y; tb.hz = r[4].z; tb.pad = r[4].w;
-      RayBox rb = ray_box_prepare(tb);
-      rb.upright = __builtin_amdgcn_readfirstlane((int)rb.upright) != 0;      // the record is the same in every lane: keep the branch scalar
-      if (rb.upright && __builtin_amdgcn_readfirstlane((int)(tb.m02 == 0.f && tb.m12 == 0.f)) != 0) {
-        // a box turned about z only (m02 = m12 = 0 exactly): lp2 = 0 * relx + 0 * rely + m22 * relz = round(m22 * relz), and relz = oz - pz is the
-        // same for every ray of the env - the two z-face parameters and their validity are properties of the BOX; a ray only decides "inside the
-        // footprint or not".  Same values as ray_box_down's two-face form, ~20 instructions per box and ray pair less
-        const float lp2 = mul_unfused(tb.m22, oz - tb.pz);      // a product on its own (the generic form adds it to two exact zeros): must not be fused into sz - lp2
-        const float xt = (tb.sz - lp2) * rb.il[2], xb = (-tb.sz - lp2) * rb.il[2];
-        float hz = xt >= 0.f ? xt : INFINITY;
-        hz = ((xb >= 0.f) & (xb < hz)) ? xb : hz;
+    auto test_box = [&](const float4 (&r)[3]) {
+      if (__builtin_amdgcn_readfirstlane(__float_as_int(r[2].y)) != 0) {        // the record is the same in every lane: a scalar branch
+        const float hz = r[2].x;
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-          const V3 rel = org[k] - v3(tb.px, tb.py, tb.pz);
-          const float lp0 = tb.m00 * rel.x + tb.m10 * rel.y, lp1 = tb.m01 * rel.x + tb.m11 * rel.y;      // + m20 * relz = + (+-0): only the sign of a zero, and |lp| is what is tested
-          const bool inside = (fabsf(lp0) <= tb.sx) & (fabsf(lp1) <= tb.sy);
+          const float rx = org[k].x - r[0].x, ry = org[k].y - r[0].y;
+          const float lp0 = r[0].z * rx + r[0].w * ry, lp1 = r[1].x * rx + r[1].y * ry;      // + m20 * relz = + (+-0): only the sign of a zero, and |lp| is what is tested
+          const bool inside = (fabsf(lp0) <= r[1].z) & (fabsf(lp1) <= r[1].w);
           hit[k] = fminf(hit[k], inside ? hz : INFINITY);
         }
         return;
       }
+      const TerrainBox tb = boxes[__builtin_amdgcn_readfirstlane(__float_as_int(r[2].z))];
+      const RayBox rb = ray_box_prepare(tb);
 #pragma unroll
       for (int k = 0; k < 2; k++) hit[k] = fminf(hit[k], ray_box_down(tb, rb, org[k]));
     };
-    float4 cur[5], nxt[5];
+    float4 cur[3], nxt[3];
     if (nslot > 0) load_slot(0, cur);
     for (int i = 0; i < nslot; i++) {
       if (i + 1 < nslot) load_slot(i + 1, nxt);
       test_box(cur);
 #pragma unroll
-      for (int q = 0; q < 5; q++) cur[q] = nxt[q];
+      for (int q = 0; q < 3; q++) cur[q] = nxt[q];
     }
 #pragma unroll
     for (int h = 0; h < 2; h++) {
