@@ -358,7 +358,12 @@ int pgtt_scan(pgtt_handle h, float yaw_override_or_nan, void* stream) {
 int pgtt_set_test_overrides(pgtt_handle h, float rng_value_or_nan, int scan_preset) {
   if (!h) return fail(PGTT_E_ARG, "null handle");
   if (!h->cfg.test_hooks) return fail(PGTT_E_STATE, "pgtt_set_test_overrides: the handle was not created with PgttConfig.test_hooks");
-  h->test_rng_fix = rng_value_or_nan; h->test_scan_preset = scan_preset != 0;
+  h->test_rng_fix = rng_value_or_nan;
+#ifdef PGTT_OBS_STOP
+  h->test_scan_preset = scan_preset;      // 100 + k: phase boundary at which the step's observe waves leave (tools/gpu_observe_instr.py)
+#else
+  h->test_scan_preset = scan_preset != 0;
+#endif
   return PGTT_OK;
 }
 

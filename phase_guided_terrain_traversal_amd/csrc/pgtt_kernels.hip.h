@@ -560,8 +560,15 @@ PG_INL void task_rewards(const float* sh_st, const float* sh_fr, const float* sh
 #ifdef PGTT_TIME
 // -DPGTT_TIME=<env> builds (tools/gpu_observe_time.py): phase ticks of the observe wave of that env at a.trace[60000 + i]
 #define PG_OTICK(i) do { if (OMODE == OBS_STEP && e == PGTT_TIME && a.trace) { long long t_ = __builtin_readcyclecounter(); if (lane == 0) a.trace[60000 + (i)] = (float)(t_ - ot0_); } } while (0)
+#elif defined(PGTT_OBS_STOP)
+// -DPGTT_OBS_STOP builds (tools/gpu_observe_instr.py): the step's observe wave leaves at phase boundary i when the test-hook integer says so
+#define PG_OTICK(i) do { if (OMODE == OBS_STEP && a.scan_preset == 100 + (i)) return; } while (0)
+#define PG_SCAN_PRESET(a) ((a).scan_preset == 1)
 #else
 #define PG_OTICK(i) ((void)0)
+#endif
+#ifndef PG_SCAN_PRESET
+#define PG_SCAN_PRESET(a) ((a).scan_preset != 0)
 #endif
 template <int OMODE, bool HAS_TERRAIN>
 // four waves per SIMD (128 VGPRs): the kernel is latency-bound, a launch lasts as long as the resident waves of a SIMD take in turn
@@ -737,7 +744,7 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
     float dist = hit[h] == INFINITY ? -1.0f : hit[h];
     z[h] = org[h].z + (-1.0f) * dist;
     int idx = lane + 64 * h;
-    if ((OMODE == OBS_STEP || OMODE == OBS_STEP_OBS) && a.scan_preset) z[h] = a.buf.scan_z[(long)e * PGTT_NSCAN + (idx < PGTT_NSCAN ? idx : 0)];   // test hook
+    if ((OMODE == OBS_STEP || OMODE == OBS_STEP_OBS) && PG_SCAN_PRESET(a)) z[h] = a.buf.scan_z[(long)e * PGTT_NSCAN + (idx < PGTT_NSCAN ? idx : 0)];   // test hook
     if (idx < PGTT_NSCAN) { sh_scan[idx] = z[h]; a.buf.scan_z[(long)e * PGTT_NSCAN + idx] = z[h]; }
   }
   if (OMODE == OBS_SCAN_ONLY) return;
@@ -921,51 +928,57 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
   if (OMODE == OBS_STEP && cfg->autoreset) {
     ep_steps += 1;
     if (ep_steps >= cfg->episode_length) wdone = true;
-    if (a.buf.ep_metrics) {
-      const float keep = prev_done ? 0.f : 1.f;
-      for (int k = lane; k < PGTT_NMETRIC + 2; k += 64) {
-        float add = k < PGTT_NMETRIC ? 0.f : (k == PGTT_NMETRIC ? reward : 1.0f);
+  }
+  // Every value below is the same in all lanes (a per-env scalar in a vector register).  Lane 0 parks them in LDS - the new values of the
+  // env's state rows in their slots of the row image sh_st, the metrics with (reward, 1) behind them - and the wave then stores ROW RANGES
+  // with one address per lane; picking "my row's value" out of registers costs a compare + select per candidate (22 for a metric) and a
+  // 64-bit address per store site, in a kernel whose four waves per SIMD share the vector ALU.
+  __shared__ float sh_met[PGTT_NMETRIC + 2];
+  __syncthreads();                       // the row image has been read for the last time (rewards, history)
+  if (lane < 12) {
+    const float prev = sh_st[PGTT_S_LAST_ACT + lane];
+    sh_st[PGTT_S_LAST_LAST_ACT + lane] = OMODE == OBS_STEP ? prev : 0.f;
+    sh_st[PGTT_S_LAST_ACT + lane] = OMODE == OBS_STEP ? act_i : 0.f;
+    if (OMODE != OBS_STEP) sh_st[PGTT_S_MOTOR_TARGETS + lane] = 0.f;
+  }
+  if (lane < 24) { sh_st[PGTT_S_QVEL_HIST + lane] = hist_v; sh_st[PGTT_S_QERR_HIST + lane] = hist_q; }
+  if (lane == 0) {
 #pragma unroll
-        for (int j = 0; j < PGTT_NMETRIC; j++) if (j == k) add = metrics[j];
-        float* p = a.buf.ep_metrics + k * (long)N + e;
-        *p = (*p + add) * keep;
-      }
+    for (int i = 0; i < 3; i++) sh_st[PGTT_S_CMD + i] = cmd[i];
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+      sh_st[PGTT_S_PHASE + f] = phase[f]; sh_st[PGTT_S_AIR_TIME + f] = air[f]; sh_st[PGTT_S_SWING_PEAK + f] = peak[f];
+      sh_st[PGTT_S_HMAX + f] = hmax[f]; sh_st[PGTT_S_HMIN + f] = hmin[f]; sh_st[PGTT_S_LAST_CONTACT + f] = last_contact[f];
     }
+    sh_st[PGTT_S_PHASE_DT] = phase_dt; sh_st[PGTT_S_GAIT_FREQ] = gait_freq;
+#pragma unroll
+    for (int k = 0; k < PGTT_NMETRIC; k++) sh_met[k] = metrics[k];
+    sh_met[PGTT_NMETRIC] = reward; sh_met[PGTT_NMETRIC + 1] = 1.0f;
+  }
+  __syncthreads();
+  if (OMODE == OBS_STEP && cfg->autoreset && a.buf.ep_metrics && lane < PGTT_NMETRIC + 2) {
+    float* p = a.buf.ep_metrics + lane * (long)N + e;
+    *p = (*p + sh_met[lane]) * (prev_done ? 0.f : 1.f);
   }
 
   PG_OTICK(6);
-  // ---------------- stores
-  if (lane < 3) S[(PGTT_S_CMD + lane) * (long)N + e] = sel4(lane, cmd[0], cmd[1], cmd[2], 0.f);
-  if (lane < 4) {
-    S[(PGTT_S_PHASE + lane) * (long)N + e] = sel4(lane, phase[0], phase[1], phase[2], phase[3]);
-    S[(PGTT_S_AIR_TIME + lane) * (long)N + e] = sel4(lane, air[0], air[1], air[2], air[3]);
-    S[(PGTT_S_SWING_PEAK + lane) * (long)N + e] = sel4(lane, peak[0], peak[1], peak[2], peak[3]);
-    S[(PGTT_S_HMAX + lane) * (long)N + e] = sel4(lane, hmax[0], hmax[1], hmax[2], hmax[3]);
-    S[(PGTT_S_HMIN + lane) * (long)N + e] = sel4(lane, hmin[0], hmin[1], hmin[2], hmin[3]);
-    S[(PGTT_S_LAST_CONTACT + lane) * (long)N + e] = sel4(lane, last_contact[0], last_contact[1], last_contact[2], last_contact[3]);
-  }
-  if (lane < 24) { S[(PGTT_S_QVEL_HIST + lane) * (long)N + e] = hist_v; S[(PGTT_S_QERR_HIST + lane) * (long)N + e] = hist_q; }
-  if (lane < 12) {
-    if (OMODE == OBS_STEP) {
-      S[(PGTT_S_LAST_LAST_ACT + lane) * (long)N + e] = sh_st[PGTT_S_LAST_ACT + lane];
-      S[(PGTT_S_LAST_ACT + lane) * (long)N + e] = act_i;
-    } else {
-      S[(PGTT_S_LAST_LAST_ACT + lane) * (long)N + e] = 0.f; S[(PGTT_S_LAST_ACT + lane) * (long)N + e] = 0.f;
-      S[(PGTT_S_MOTOR_TARGETS + lane) * (long)N + e] = 0.f;
-    }
+  // ---------------- stores: rows PGTT_S_CMD .. PGTT_NSTATE - 1 of the image (the step leaves the motor targets, which are the physics kernel's, alone)
+  static_assert(PGTT_NSTATE - PGTT_S_CMD <= 128 && PGTT_NMETRIC + 2 <= 64, "two passes over the rows, one over the metrics");
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int r = PGTT_S_CMD + lane + 64 * h;
+    const bool mine = r < PGTT_NSTATE && (OMODE != OBS_STEP || r < PGTT_S_MOTOR_TARGETS || r >= PGTT_S_MOTOR_TARGETS + 12);
+    if (mine) S[r * (long)N + e] = sh_st[r];
   }
   if (lane == 0) {
-    S[PGTT_S_PHASE_DT * (long)N + e] = phase_dt; S[PGTT_S_GAIT_FREQ * (long)N + e] = gait_freq;
     I[PGTT_I_STEP * (long)N + e] = step_ctr; I[PGTT_I_STEPS_UNTIL_CMD * (long)N + e] = timer;
     I[PGTT_I_RNG_CTR * (long)N + e] = (int)(ep + 1u); I[PGTT_I_EP_STEPS * (long)N + e] = ep_steps;
     a.buf.reward[e] = reward; a.buf.done[e] = wdone ? 1.f : 0.f;
   }
-  for (int k = lane; k < PGTT_NMETRIC; k += 64) {
-    float v = 0.f;
-#pragma unroll
-    for (int j = 0; j < PGTT_NMETRIC; j++) if (j == k) v = metrics[j];
-    a.buf.metrics[k * (long)N + e] = v;
-    if (OMODE == OBS_STEP && a.buf.interval_sums) a.buf.interval_sums[k * (long)N + e] += v;
+  if (lane < PGTT_NMETRIC) {
+    const float v = sh_met[lane];
+    a.buf.metrics[lane * (long)N + e] = v;
+    if (OMODE == OBS_STEP && a.buf.interval_sums) a.buf.interval_sums[lane * (long)N + e] += v;
   }
   if (OMODE == OBS_STEP && a.buf.interval_sums && lane < 2)
     a.buf.interval_sums[(PGTT_NMETRIC + lane) * (long)N + e] += lane == 0 ? reward : (wdone ? 1.f : 0.f);
