@@ -222,6 +222,10 @@ struct QSim {
   // outputs
   float qacc_b[6], qacc_l[3];
   int niter, niter_max;
+#ifdef PGTT_EFFORT
+  // -DPGTT_EFFORT builds (tools/gpu_effort.py): 1 + the line-search rounds THIS env needed, 3 bits per Newton trip, 5 trips per substep
+  unsigned long long eff = 0ull; int eff_pos = 0, eff_sub = 0;
+#endif
   bool pen_overflow;         // some substep of this call met more than kMaxPenQ simultaneously penetrating boxes under this foot (collide())
 };
 
@@ -1626,9 +1630,15 @@ struct QSolver {
     LSPoint hi = lesser ? p0 : lo0, lo = lesser ? lo0 : p0;
     bool swap = true; int it = 0;
     PG_LTICK(s, 21);      // the two initial points
+#ifdef PGTT_EFFORT
+    int eff_need = frozen ? 0 : 1;        // 0: the env was not in this trip at all
+#endif
     for (;;) {
       bool done = it >= m->ls_iterations || !swap || ((lo.d0 < 0.f) && (lo.d0 > -gtol)) || ((hi.d0 > 0.f) && (hi.d0 < gtol));
       if (__ballot(!done) == 0ull) break;
+#ifdef PGTT_EFFORT
+      eff_need += (done || frozen) ? 0 : 1;
+#endif
 #ifdef PGTT_TIME
       s.cyc[18] += 1.f;           // line-search rounds executed by this wave
       s.cyc[19] += done ? 0.f : 1.f;   // ... of which this env needed
@@ -1643,6 +1653,9 @@ struct QSolver {
       swap = ml | mh; it++;
     }
     PG_LTICK(s, 22);      // bracketing rounds
+#ifdef PGTT_EFFORT
+    s.eff |= (unsigned long long)eff_need << s.eff_pos; s.eff_pos += 3;
+#endif
     {   // costs of the two points the bracket ended with
       const float al2[2] = {lo.alpha, hi.alpha};
       LSPoint fin[2];
@@ -1675,6 +1688,9 @@ struct QSolver {
   }
 
   PG_INL void solve() {
+#ifdef PGTT_EFFORT
+    s.eff_pos = 15 * s.eff_sub; s.eff_sub++;
+#endif
     int nb = 0;
 #pragma unroll
     for (int k = 0; k < kMaxB; k++) if (__ballot(s.nbox > k) != 0ull) nb = k + 1;
