@@ -49,6 +49,7 @@ struct pgtt_env {
   unsigned long long seed = 0;
   long long env_off = 0;
   float test_rng_fix = NAN; int test_scan_preset = 0;   // pgtt_set_test_overrides
+  float* d_handover = nullptr;    // [N][kHandover]: physics -> observe hand-over of one pgtt_step (pgtt_kernels.hip.h, KArgs)
   bool timing = false;
   int timing_period = 1, timing_tick = 0; bool timing_now = false;   // time every timing_period-th step (event records cost ~3 us of GPU idle each)
   bool split_observe = false;     // observe = observe_kernel<OBS_STEP_OBS> + task_kernel (PgttConfig.observe_form)
@@ -84,6 +85,7 @@ pgtt::KArgs make_args(pgtt_env* h, const unsigned char* mask, float yaw_override
   a.model = h->d_model; a.cfg = h->d_cfg; a.terrain = h->d_terrain; a.T = h->T; a.B = h->B; a.grid = h->d_grid; a.grid_E = h->grid_E; a.grid_inv = h->grid_inv;
   a.buf = h->buf; a.N = h->N; a.seed = h->seed; a.env_off = h->env_off; a.mask = mask; a.yaw_override = yaw_override; a.write_qpos = 0;
   a.rng_fix = h->test_rng_fix; a.scan_preset = h->test_scan_preset;
+  a.handover_w = h->d_handover; a.handover_r = nullptr;
 #if defined(PGTT_TRACE) || defined(PGTT_TIME)
   a.trace = pgtt_trace_buffer();
 #endif
@@ -189,6 +191,7 @@ int pgtt_create(const PgttConfig* cfg, const PgttModel* model, int device, int n
   h->split_observe = cfg->observe_form == PGTT_OBSERVE_SPLIT;
   HIP_TRY(hipMalloc(&h->d_cfg, sizeof(PgttConfig)));
   HIP_TRY(hipMalloc(&h->d_model, sizeof(PgttModel)));
+  HIP_TRY(hipMalloc(&h->d_handover, (size_t)num_envs * pgtt::kHandover * sizeof(float)));
   HIP_TRY(hipMemcpy(h->d_cfg, cfg, sizeof(PgttConfig), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->d_model, model, sizeof(PgttModel), hipMemcpyHostToDevice));
   for (int r = 0; r < pgtt_env::kRing; r++) for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&h->ev[r][i]));
@@ -201,6 +204,7 @@ int pgtt_destroy(pgtt_handle h) {
   hipSetDevice(h->device);
   if (h->d_cfg) hipFree(h->d_cfg);
   if (h->d_model) hipFree(h->d_model);
+  if (h->d_handover) hipFree(h->d_handover);
   if (h->d_terrain) hipFree(h->d_terrain);
   if (h->d_grid) hipFree(h->d_grid);
   for (int r = 0; r < pgtt_env::kRing; r++) for (int i = 0; i < 4; i++) if (h->ev[r][i]) hipEventDestroy(h->ev[r][i]);
@@ -321,12 +325,15 @@ int pgtt_physics(pgtt_handle h, const float* action, void* stream) {
   return PGTT_OK;
 }
 
-int pgtt_observe(pgtt_handle h, const float* action, void* stream) {
+// same_step: called by pgtt_step right behind this step's physics launch on the same stream - the observe kernel may then take the physics
+// outputs from the hand-over record instead of the caller-visible rows (which it must use when the caller had a chance to edit them)
+static int observe_impl(pgtt_handle h, const float* action, void* stream, bool same_step) {
   if (int rc = check_ready(h)) return rc;
   if (!action) return fail(PGTT_E_ARG, "pgtt_observe: null action");
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   pgtt::KArgs a = make_args(h, nullptr, 0.f);
+  if (same_step) a.handover_r = h->d_handover;
   const bool timed = h->timing_now && h->ev_slot >= 0;
   if (timed) HIP_TRY(hipEventRecord(h->ev[h->ev_slot][2], st));
   if (h->split_observe) {
@@ -341,9 +348,11 @@ int pgtt_observe(pgtt_handle h, const float* action, void* stream) {
   return PGTT_OK;
 }
 
+int pgtt_observe(pgtt_handle h, const float* action, void* stream) { return observe_impl(h, action, stream, false); }
+
 int pgtt_step(pgtt_handle h, const float* action, void* stream) {
   if (int rc = pgtt_physics(h, action, stream)) return rc;
-  return pgtt_observe(h, action, stream);
+  return observe_impl(h, action, stream, true);
 }
 
 int pgtt_scan(pgtt_handle h, float yaw_override_or_nan, void* stream) {

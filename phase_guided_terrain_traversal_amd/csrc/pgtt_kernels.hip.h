@@ -35,6 +35,14 @@ struct KArgs {
   // fixtures hold scan values, not terrains)
   float rng_fix;
   int scan_preset;
+  // Hand-over record of a control step, env-major [N][kHandover]: what the physics kernel computes and the observe kernel of the SAME
+  // pgtt_step reads (qpos, qvel, motor targets, sensor frame).  The caller-visible rows stay the SoA [row][N] buffers, written as before;
+  // but a wave that reads ITS env's 114 values out of them makes 114 requests for 128-byte lines, and the observe launch spends its first
+  // ~5 us doing that (one request in ~23 ns per env, measured by leaving rows out).  From the record they are two coalesced loads.
+  // handover_w: the physics launch writes it (every MODE_STEP launch does); handover_r: the observe launch may read it (pgtt_step only -
+  // between pgtt_physics and pgtt_observe called on their own the caller may have edited the rows).
+  float* handover_w;
+  const float* handover_r;
 #if defined(PGTT_TRACE) || defined(PGTT_TIME)
   float* trace;                // debugging builds only: per-iteration solver record of env 0
 #endif
@@ -68,6 +76,9 @@ PG_INL int exp_timer(unsigned long long seed, unsigned env, unsigned epoch, unsi
 }
 
 enum { MODE_STEP = 0, MODE_FORWARD = 1 };
+constexpr int kHandover = 128;                 // floats per env (512 bytes: four lines)
+enum { HO_QPOS = 0, HO_QVEL = 19, HO_MOTOR = 37, HO_FRAME = 49, HO_END = HO_FRAME + PGTT_NFRAME };
+static_assert(HO_END <= kHandover, "hand-over record");
 
 // Workgroup i is dispatched to XCD i % 8 and every XCD has its own L2.  Rows of the SoA state are contiguous over envs,
 // so neighbouring envs share 128-byte lines: give each XCD a CONTIGUOUS range of logical blocks (MI355X_MICROARCH.md,
@@ -181,7 +192,9 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
       for (int k = 0; k < 3; k++) cacc = cacc + s.cddr[k] * s.vb[3 + k];
       V3 a0 = mtmul(s.R0, cacc.l - cross(dif, cacc.a)) + cross(gyro, llin);
       acc0[0] = a0.x; acc0[1] = a0.y; acc0[2] = a0.z;
-      auto put3 = [&](int row, V3 v) { Fr[row * (long)N + ee] = v.x; Fr[(row + 1) * (long)N + ee] = v.y; Fr[(row + 2) * (long)N + ee] = v.z; };
+      float* __restrict__ Ho = a.handover_w + (long)ee * kHandover + HO_FRAME;      // MODE_STEP: the same values, env-major, for this step's observe launch
+      auto put1 = [&](int row, float v) { Fr[row * (long)N + ee] = v; if (MODE == MODE_STEP) Ho[row] = v; };
+      auto put3 = [&](int row, V3 v) { put1(row, v.x); put1(row + 1, v.y); put1(row + 2, v.z); };
       if (lead) {
         put3(PGTT_F_GYRO, gyro); put3(PGTT_F_GLOBAL_LINVEL, glin); put3(PGTT_F_GLOBAL_ANGVEL, w); put3(PGTT_F_LOCAL_LINVEL, llin);
         put3(PGTT_F_UPVECTOR, v3(s.R0.m[2], s.R0.m[5], s.R0.m[8]));
@@ -201,10 +214,10 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
         put3(PGTT_F_FEET_POS + 3 * f, mtmul(s.R0, s.sitef - s.imu));
         S6 cv = s.cvell[2];
         put3(PGTT_F_FEET_VEL + 3 * f, cv.l - cross(s.sitef - s.com, cv.a));
-        Fr[(PGTT_F_CONTACT + f) * (long)N + ee] = touching ? 1.0f : 0.0f;
-        Fr[(PGTT_F_FOOT_SITE_Z + f) * (long)N + ee] = s.sitef.z;
+        put1(PGTT_F_CONTACT + f, touching ? 1.0f : 0.0f);
+        put1(PGTT_F_FOOT_SITE_Z + f, s.sitef.z);
 #pragma unroll
-        for (int k = 0; k < 3; k++) Fr[(PGTT_F_ACT_FORCE + 3 * f + k) * (long)N + ee] = s.act_force[k];
+        for (int k = 0; k < 3; k++) put1(PGTT_F_ACT_FORCE + 3 * f + k, s.act_force[k]);
         if (a.buf.dbg_contact && a.buf.dbg_dist) {
           int* dc = a.buf.dbg_contact + (long)ee * 16; float* dd = a.buf.dbg_dist + (long)ee * 8;
           dc[2 * l] = l; dc[2 * l + 1] = -1; dd[l] = s.con0.dist;
@@ -238,6 +251,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
 #pragma unroll
         for (int k = 0; k < 6; k++) v += accA[r][k] * s.qacc_b[k];
         Fr[(PGTT_F_ACCEL + r) * (long)N + ee] = v;
+        if (MODE == MODE_STEP) a.handover_w[(long)ee * kHandover + HO_FRAME + PGTT_F_ACCEL + r] = v;
       }
       if (a.buf.dbg_niter) a.buf.dbg_niter[ee] = s.niter_max | (pen_ovf > 0 ? PGTT_DBG_PEN_OVERFLOW : 0);
     }
@@ -302,6 +316,15 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
     for (int k = 0; k < 3; k++) {
       S[(PGTT_S_QVEL + 6 + 3 * l + k) * (long)N + e] = s.vl[k];
       S[(PGTT_S_MOTOR_TARGETS + 3 * (l ^ 1) + k) * (long)N + e] = s.ctrl[k];
+    }
+    float* __restrict__ Ho = a.handover_w + (long)e * kHandover;
+#pragma unroll
+    for (int i = 0; i < 7; i++) Ho[HO_QPOS + i] = s.qb[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) Ho[HO_QVEL + i] = s.vb[i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      Ho[HO_QPOS + 7 + 3 * l + k] = s.ql[k]; Ho[HO_QVEL + 6 + 3 * l + k] = s.vl[k]; Ho[HO_MOTOR + 3 * (l ^ 1) + k] = s.ctrl[k];
     }
   }
 #pragma unroll
@@ -562,7 +585,8 @@ PG_INL void task_rewards(const float* sh_st, const float* sh_fr, const float* sh
 
 #ifdef PGTT_TIME
 // -DPGTT_TIME=<env> builds (tools/gpu_observe_time.py): phase ticks of the observe wave of that env at a.trace[60000 + i]
-#define PG_OTICK(i) do { if (OMODE == OBS_STEP && e == PGTT_TIME && a.trace) { long long t_ = __builtin_readcyclecounter(); if (lane == 0) a.trace[60000 + (i)] = (float)(t_ - ot0_); } } while (0)
+#define PG_OTICK(i) do { if (OMODE == OBS_STEP && a.trace) { long long t_ = __builtin_readcyclecounter(); if (lane == 0) { if (e == PGTT_TIME) a.trace[60000 + (i)] = (float)(t_ - ot0_); \
+    if (blockIdx.x < 4096) a.trace[65536 + 8 * blockIdx.x + (i)] = (float)(t_ - ot0_); } } } while (0)        /* [65536 + 8 block + i]: every wave's boundaries */
 #elif defined(PGTT_OBS_STOP)
 // -DPGTT_OBS_STOP builds (tools/gpu_observe_instr.py): the step's observe wave leaves at phase boundary i when the test-hook integer says so
 #define PG_OTICK(i) do { if (OMODE == OBS_STEP && a.scan_preset == 100 + (i)) return; } while (0)
@@ -607,8 +631,32 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
       brec[h][0] = reinterpret_cast<const float4*>(boxes + b)[0]; brec[h][1] = reinterpret_cast<const float4*>(boxes + b)[4];
     }
   }
-  for (int r = lane; r < PGTT_NSTATE; r += 64) sh_st[r] = S[r * (long)N + e];
-  for (int r = lane; r < PGTT_NFRAME; r += 64) sh_fr[r] = a.buf.frame[r * (long)N + e];
+  if (OMODE == OBS_STEP && a.handover_r) {
+    // this step's physics launch left qpos, qvel, the motor targets and the sensor frame env-major: two coalesced loads.  Of the other rows
+    // the step reads PGTT_S_CMD .. PGTT_NSTATE - 1 without H_max / H_min (formed anew from this step's scan) and the older halves of the two
+    // histories - not the warm start either
+    const float* __restrict__ Hr = a.handover_r + (long)e * kHandover;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int j = lane + 64 * h;
+      if (j < HO_END) {
+        const float v = Hr[j];
+        if (j < HO_MOTOR) sh_st[j] = v;                     // qpos, qvel: rows 0 .. 36 in the same order
+        else if (j < HO_FRAME) sh_st[PGTT_S_MOTOR_TARGETS + j - HO_MOTOR] = v;
+        else sh_fr[j - HO_FRAME] = v;
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int r = PGTT_S_CMD + lane + 64 * h;
+      const bool need = r < PGTT_NSTATE && !(r >= PGTT_S_HMAX && r < PGTT_S_HMIN + 4) && !(r >= PGTT_S_MOTOR_TARGETS && r < PGTT_S_MOTOR_TARGETS + 12) &&
+                        !(r >= PGTT_S_QERR_HIST + 12 && r < PGTT_S_QERR_HIST + 24) && !(r >= PGTT_S_QVEL_HIST + 12 && r < PGTT_S_QVEL_HIST + 24);     // the older half of a history only ever leaves
+      if (need) sh_st[r] = S[r * (long)N + e];
+    }
+  } else {
+    for (int r = lane; r < PGTT_NSTATE; r += 64) sh_st[r] = S[r * (long)N + e];
+    for (int r = lane; r < PGTT_NFRAME; r += 64) sh_fr[r] = a.buf.frame[r * (long)N + e];
+  }
   if (OMODE == OBS_STEP && lane < 12) sh_act[lane] = action[(long)e * 12 + lane];
   __syncthreads();
   PG_OTICK(0);
@@ -970,7 +1018,8 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     const int r = PGTT_S_CMD + lane + 64 * h;
-    const bool mine = r < PGTT_NSTATE && (OMODE != OBS_STEP || r < PGTT_S_MOTOR_TARGETS || r >= PGTT_S_MOTOR_TARGETS + 12);
+    // the step leaves the histories alone except on the steps that shift them (1 in history_update_steps)
+    const bool mine = r < PGTT_NSTATE && (OMODE != OBS_STEP || r < PGTT_S_MOTOR_TARGETS || r >= PGTT_S_LAST_CONTACT || (upd && r >= PGTT_S_QERR_HIST));
     if (mine) S[r * (long)N + e] = sh_st[r];
   }
   if (lane == 0) {

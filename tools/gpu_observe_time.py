@@ -25,6 +25,11 @@ for k in range(60):
 print(f"{wl}: observe wave of env 0, mean over {cnt} steps, total {acc.sum() / cnt:.0f} ticks")
 for nme, v in zip(names, acc / cnt):
     print(f"  {nme:34s} {v:9.0f} ticks  {100 * v / acc.sum() * cnt:5.1f} %")
+allw = np.diff(np.concatenate([np.zeros((4096, 1)), buf[65536:65536 + 8 * 4096].reshape(4096, 8).astype(np.float64)], 1), axis=1)
+print("last launch, all 4096 waves: ticks per phase, quantiles 10 / 50 / 90 / 100 %")
+for i, nme in enumerate(names):
+    print(f"  {nme:34s}", " ".join(f"{q:7.0f}" for q in np.percentile(allw[:, i], [10, 50, 90, 100])))
+print(f"  {'whole wave':34s}", " ".join(f"{q:7.0f}" for q in np.percentile(allw.sum(1), [10, 50, 90, 100])))
 tw = buf[40960:40960 + 4 * 4096].view(np.uint32).reshape(-1, 4)
 tw = tw[tw[:, 3] != 0]
 hw, xcc, t0, t1 = tw[:, 0], tw[:, 1] & 0xF, tw[:, 2].astype(np.int64), tw[:, 3].astype(np.int64)
