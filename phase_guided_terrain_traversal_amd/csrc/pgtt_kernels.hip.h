@@ -658,6 +658,13 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
     for (int r = lane; r < PGTT_NFRAME; r += 64) sh_fr[r] = a.buf.frame[r * (long)N + e];
   }
   if (OMODE == OBS_STEP && lane < 12) sh_act[lane] = action[(long)e * 12 + lane];
+  // the running sums this step adds to (rows of this env, touched by this wave only) are requested here, a launch ahead of their use:
+  // at the end of the wave nothing is left to hide a round trip behind
+  float epm_old = 0.f, ivs_old = 0.f;
+  if (OMODE == OBS_STEP && lane < PGTT_NMETRIC + 2) {
+    if (a.buf.ep_metrics) epm_old = a.buf.ep_metrics[lane * (long)N + e];
+    if (a.buf.interval_sums) ivs_old = a.buf.interval_sums[lane * (long)N + e];
+  }
   __syncthreads();
   PG_OTICK(0);
 
@@ -1007,10 +1014,8 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
     sh_met[PGTT_NMETRIC] = reward; sh_met[PGTT_NMETRIC + 1] = 1.0f;
   }
   __syncthreads();
-  if (OMODE == OBS_STEP && cfg->autoreset && a.buf.ep_metrics && lane < PGTT_NMETRIC + 2) {
-    float* p = a.buf.ep_metrics + lane * (long)N + e;
-    *p = (*p + sh_met[lane]) * (prev_done ? 0.f : 1.f);
-  }
+  if (OMODE == OBS_STEP && cfg->autoreset && a.buf.ep_metrics && lane < PGTT_NMETRIC + 2)
+    a.buf.ep_metrics[lane * (long)N + e] = (epm_old + sh_met[lane]) * (prev_done ? 0.f : 1.f);
 
   PG_OTICK(6);
   // ---------------- stores: rows PGTT_S_CMD .. PGTT_NSTATE - 1 of the image (the step leaves the motor targets, which are the physics kernel's, alone)
@@ -1030,10 +1035,9 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
   if (lane < PGTT_NMETRIC) {
     const float v = sh_met[lane];
     a.buf.metrics[lane * (long)N + e] = v;
-    if (OMODE == OBS_STEP && a.buf.interval_sums) a.buf.interval_sums[lane * (long)N + e] += v;
   }
-  if (OMODE == OBS_STEP && a.buf.interval_sums && lane < 2)
-    a.buf.interval_sums[(PGTT_NMETRIC + lane) * (long)N + e] += lane == 0 ? reward : (wdone ? 1.f : 0.f);
+  if (OMODE == OBS_STEP && a.buf.interval_sums && lane < PGTT_NMETRIC + 2)
+    a.buf.interval_sums[lane * (long)N + e] = ivs_old + (lane < PGTT_NMETRIC ? sh_met[lane] : (lane == PGTT_NMETRIC ? reward : (wdone ? 1.f : 0.f)));
   const bool restore = OMODE == OBS_STEP && cfg->autoreset && wdone && a.buf.first_state && a.buf.first_obs;
   if (restore) {
     for (int r = lane; r < PGTT_S_CMD; r += 64) S[r * (long)N + e] = a.buf.first_state[r * (long)N + e];
