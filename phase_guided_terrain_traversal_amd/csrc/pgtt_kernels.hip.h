@@ -597,6 +597,56 @@ PG_INL void task_rewards(const float* sh_st, const float* sh_fr, const float* sh
 #ifndef PG_SCAN_PRESET
 #define PG_SCAN_PRESET(a) ((a).scan_preset != 0)
 #endif
+// ---- observation rows as a table.  Every row of the state observation is (source value [- zmin]) [+ noise] [- offset]; which source, which
+// word of the noise draws, which noise scale and which offset is a function of the row number alone.  The kernel used to find them through a
+// chain of row-range tests that every lane of every pass walked (the vector ALU is what the four waves of a SIMD share); now lane io reads
+// descriptor io - byte offsets into ONE LDS array that holds the state rows, the sensor frame, the scan and the per-env scalars - and the
+// pass is four LDS reads and ~20 vector instructions.  Layout of the array (floats):
+enum { OL_ST = 0, OL_FR = OL_ST + PGTT_NSTATE, OL_SCAN = OL_FR + PGTT_NFRAME, OL_DRV = OL_SCAN + 128,
+       OD_PHASE = 0 /* cos x4, sin x4 */, OD_GAIT = 8, OD_CMD = 9, OD_ZERO = 12, OD_LASTC = 13, OD_AIR = 17,
+       OD_SCALE = 21 /* 0, gyro, gravity, joint pos, joint vel, scan */, OD_OFFS = 27 /* 0, key_qpos[7..18] */, OD_END = 40, OL_END = OL_DRV + OD_END };
+constexpr int kObsRowSlots = 192, kPrivSlots = 64;
+struct ObsRowTab { unsigned row[2][kObsRowSlots]; unsigned short priv[kPrivSlots]; };
+// descriptor: bits 0..10 byte offset of the source, 11..20 byte offset of the noise word in sh_rng, 21..25 byte offset of the scale in
+// OD_SCALE (20 = scan: the row is taken relative to zmin), 26..31 byte offset of the offset in OD_OFFS
+constexpr unsigned obs_row_desc(int i) {       // i = row in the PGTT layout (joystick_pgtt.py:336-349)
+  unsigned src = 0, word = 0, scale = 0, offs = 0;
+  if (i < 3) { src = OL_FR + PGTT_F_GYRO + i; word = i; scale = 1; }
+  else if (i < 6) { src = OL_FR + PGTT_F_GRAVITY + i - 3; word = 4 + i - 3; scale = 2; }
+  else if (i < 18) { src = OL_ST + PGTT_S_QPOS + 7 + i - 6; word = 8 + i - 6; scale = 3; offs = 1 + i - 6; }
+  else if (i < 30) { src = OL_ST + PGTT_S_QVEL + 6 + i - 18; word = 20 + i - 18; scale = 4; }
+  else if (i < 38) { src = OL_DRV + OD_PHASE + i - 30; }
+  else if (i < 38 + PGTT_NSCAN) { src = OL_SCAN + i - 38; word = 32 + i - 38; scale = 5; }
+  else if (i == 38 + PGTT_NSCAN) { src = OL_DRV + OD_GAIT; }
+  else if (i < 39 + PGTT_NSCAN + 12) { src = OL_ST + PGTT_S_LAST_ACT + i - (39 + PGTT_NSCAN); }
+  else if (i < 39 + PGTT_NSCAN + 15) { src = OL_DRV + OD_CMD + i - (51 + PGTT_NSCAN); }
+  else { src = OL_DRV + OD_ZERO; }
+  return (src * 4u) | ((word * 4u) << 11) | ((scale * 4u) << 21) | ((offs * 4u) << 26);
+}
+constexpr unsigned short obs_priv_src(int i) {    // the 44 privileged extras (joystick_pgtt.py:355-365)
+  int src = OL_DRV + OD_ZERO;
+  if (i < 3) src = OL_FR + PGTT_F_LOCAL_LINVEL + i;
+  else if (i < 6) src = OL_FR + PGTT_F_ACCEL + i - 3;
+  else if (i < 9) src = OL_FR + PGTT_F_GLOBAL_ANGVEL + i - 6;
+  else if (i < 21) src = OL_FR + PGTT_F_ACT_FORCE + i - 9;
+  else if (i < 25) src = OL_DRV + OD_LASTC + i - 21;
+  else if (i < 37) src = OL_FR + PGTT_F_FEET_VEL + i - 25;
+  else if (i < 41) src = OL_DRV + OD_AIR + i - 37;
+  return (unsigned short)(src * 4);
+}
+constexpr ObsRowTab make_obs_row_tab() {
+  ObsRowTab t{};
+  for (int io = 0; io < kObsRowSlots; io++) {
+    t.row[0][io] = obs_row_desc(io);
+    // the baseline layout (go2/joystick.py) drops rows 30..37 (phase) and 38 + NSCAN (gait_freq)
+    t.row[1][io] = obs_row_desc(io < 30 ? io : (io < 30 + PGTT_NSCAN ? io + 8 : io + 9));
+  }
+  for (int i = 0; i < kPrivSlots; i++) t.priv[i] = obs_priv_src(i);
+  return t;
+}
+static_assert(OL_END * 4 < 2048 && (8 + (PGTT_NSCAN + 3) / 4) * 16 <= 1024 && PGTT_OBS <= kObsRowSlots && PGTT_PRIV - PGTT_OBS <= kPrivSlots, "descriptor fields");
+__device__ const ObsRowTab kObsRowTab = make_obs_row_tab();
+
 template <int OMODE, bool HAS_TERRAIN>
 // four waves per SIMD (128 VGPRs): the kernel is latency-bound, a launch lasts as long as the resident waves of a SIMD take in turn
 __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __restrict__ action) {
@@ -611,9 +661,8 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
   float* __restrict__ S = a.buf.state;
   int* __restrict__ I = a.buf.istate;
 
-  __shared__ float sh_st[PGTT_NSTATE];
-  __shared__ float sh_fr[PGTT_NFRAME];
-  __shared__ float sh_scan[128];
+  __shared__ float sh_src[OL_END];
+  float* const sh_st = sh_src + OL_ST; float* const sh_fr = sh_src + OL_FR; float* const sh_scan = sh_src + OL_SCAN; float* const sh_drv = sh_src + OL_DRV;
   __shared__ float sh_obs[PGTT_OBS + PGTT_PRIV + 2];
   __shared__ float sh_act[12];
 
@@ -658,6 +707,12 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
     for (int r = lane; r < PGTT_NFRAME; r += 64) sh_fr[r] = a.buf.frame[r * (long)N + e];
   }
   if (OMODE == OBS_STEP && lane < 12) sh_act[lane] = action[(long)e * 12 + lane];
+  // row descriptors of the three passes over the observation and of the privileged extras (constants: requested with the state rows)
+  const bool baseline = cfg->method == PGTT_METHOD_BASELINE;
+  unsigned rdesc[3]; unsigned psrc;
+#pragma unroll
+  for (int it = 0; it < 3; it++) rdesc[it] = kObsRowTab.row[baseline ? 1 : 0][lane + 64 * it];
+  psrc = kObsRowTab.priv[lane];
   // the running sums this step adds to (rows of this env, touched by this wave only) are requested here, a launch ahead of their use:
   // at the end of the wave nothing is left to hide a round trip behind
   float epm_old = 0.f, ivs_old = 0.f;
@@ -836,7 +891,6 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
   // ---------------- per-env scalars (computed redundantly by every lane from LDS)
   // method 1 = the baseline task go2/joystick.py: no phase / gait_freq rows in the observation (162 / 206 instead of
   // 171 / 215), H_max = quadrant max, world-frame clearance target, 0.5 s air-time threshold
-  const bool baseline = cfg->method == PGTT_METHOD_BASELINE;
   const int OBSD = baseline ? PGTT_OBS_BASELINE : PGTT_OBS, PRIVD = OBSD + (PGTT_PRIV - PGTT_OBS);
   const unsigned id = (unsigned)(a.env_off + e);
   const unsigned ep = (unsigned)I[PGTT_I_RNG_CTR * (long)N + e];
@@ -897,43 +951,42 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
     philox4x32_10((unsigned)a.seed, (unsigned)(a.seed >> 32), c0, c1, c2, c3);
     sh_rng[4 * lane + 0] = c0; sh_rng[4 * lane + 1] = c1; sh_rng[4 * lane + 2] = c2; sh_rng[4 * lane + 3] = c3;
   }
+  // the per-env scalars the rows draw on, next to the rows' other sources: phase rows (cos x4, sin x4: ONE sincos evaluation by eight lanes),
+  // gait frequency, command, last contact, air time, the five noise scales and the twelve joint offsets
+  if (!baseline && lane < 8) {      // the baseline observation has no phase rows
+    float sn, cs; sincosf(sel4(lane & 3, phase[0], phase[1], phase[2], phase[3]), &sn, &cs);
+    sh_drv[OD_PHASE + lane] = lane < 4 ? cs : sn;
+  }
+  if (lane < 12) sh_drv[OD_OFFS + 1 + lane] = m->key_qpos[7 + lane];
+  if (lane == 0) {
+    sh_drv[OD_GAIT] = gait_freq; sh_drv[OD_ZERO] = 0.f; sh_drv[OD_OFFS] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) sh_drv[OD_CMD + k] = cmd[k];
+#pragma unroll
+    for (int f = 0; f < 4; f++) { sh_drv[OD_LASTC + f] = last_contact[f]; sh_drv[OD_AIR + f] = air[f]; }
+    sh_drv[OD_SCALE + 0] = 0.f; sh_drv[OD_SCALE + 1] = cfg->noise_gyro; sh_drv[OD_SCALE + 2] = cfg->noise_gravity;
+    sh_drv[OD_SCALE + 3] = cfg->noise_joint_pos; sh_drv[OD_SCALE + 4] = cfg->noise_joint_vel; sh_drv[OD_SCALE + 5] = cfg->noise_heightscan;
+  }
   __syncthreads();
-  for (int io = lane; io < OBSD; io += 64) {
-    // i = row in the PGTT layout; the baseline layout drops rows 30..37 (phase) and 38 + NSCAN (gait_freq)
-    const int i = !baseline ? io : (io < 30 ? io : (io < 30 + PGTT_NSCAN ? io + 8 : io + 9));
-    // every row is (base + noise) - offset with noise = (2u - 1) * level * scale: the arms only pick the operands and the
-    // word of sh_rng that holds the row's draw (rows without noise read a word too, with scale 0)
-    float base, scale = 0.f, offs = 0.f; int rblk = 0, sidx = 0;       // rblk: lane that formed block 0 of the row's stream
-    if (i < 3) { base = sh_fr[PGTT_F_GYRO + i]; rblk = 0; sidx = i; scale = cfg->noise_gyro; }
-    else if (i < 6) { base = sh_fr[PGTT_F_GRAVITY + i - 3]; rblk = 1; sidx = i - 3; scale = cfg->noise_gravity; }
-    else if (i < 18) { base = sh_st[PGTT_S_QPOS + 7 + i - 6]; rblk = 2; sidx = i - 6; scale = cfg->noise_joint_pos; offs = m->key_qpos[7 + i - 6]; }
-    else if (i < 30) { base = sh_st[PGTT_S_QVEL + 6 + i - 18]; rblk = 5; sidx = i - 18; scale = cfg->noise_joint_vel; }
-    else if (i < 38) {       // rows 30..33 cos(phase), 34..37 sin(phase): ONE sincos evaluation for the eight lanes instead of a cosf and a sinf expansion
-      float sn, cs; sincosf(sel4((i - 30) & 3, phase[0], phase[1], phase[2], phase[3]), &sn, &cs);
-      base = i < 34 ? cs : sn;
-    }
-    else if (i < 38 + PGTT_NSCAN) { base = sh_scan[i - 38] - zmin; rblk = 8; sidx = i - 38; scale = cfg->noise_heightscan; }
-    else if (i == 38 + PGTT_NSCAN) base = gait_freq;
-    else if (i < 39 + PGTT_NSCAN + 12) base = sh_st[PGTT_S_LAST_ACT + i - (39 + PGTT_NSCAN)];
-    else base = sel4(i - (51 + PGTT_NSCAN), cmd[0], cmd[1], cmd[2], 0.f);
-    const float uw = (float)(sh_rng[4 * rblk + sidx] >> 8) * (1.0f / 16777216.0f);     // word sidx & 3 of block rblk + (sidx >> 2)
+  const char* const srcb = reinterpret_cast<const char*>(sh_src);
+#pragma unroll
+  for (int it = 0; it < 3; it++) {
+    const int io = lane + 64 * it;
+    if (io >= OBSD) continue;
+    // every row is (base + noise) - offset with noise = (2u - 1) * level * scale (rows without noise read a word too, with scale 0; rows
+    // without an offset subtract the table's zero: x - 0 is x)
+    const unsigned d = rdesc[it], so = (d >> 21) & 0x1fu;
+    const float base0 = *reinterpret_cast<const float*>(srcb + (d & 0x7ffu));
+    const unsigned word = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(sh_rng) + ((d >> 11) & 0x3ffu));
+    const float scale = *reinterpret_cast<const float*>(srcb + (OL_DRV + OD_SCALE) * 4 + so);
+    const float offs = *reinterpret_cast<const float*>(srcb + (OL_DRV + OD_OFFS) * 4 + (d >> 26));
+    const float base = base0 - (so == 20u ? zmin : 0.f);              // scan rows are heights above the lowest scan point
+    const float uw = (float)(word >> 8) * (1.0f / 16777216.0f);
     const float u = a.rng_fix == a.rng_fix ? a.rng_fix : uw;
     const float noisy = scale != 0.f ? base + (2.f * u - 1.f) * lvl * scale : base;
-    const float v = offs != 0.f ? noisy - offs : noisy;
-    sh_obs[io] = v;
+    sh_obs[io] = noisy - offs;
   }
-  if (lane < PGTT_PRIV - PGTT_OBS) {
-    int i = lane; float v;
-    if (i < 3) v = sh_fr[PGTT_F_LOCAL_LINVEL + i];
-    else if (i < 6) v = sh_fr[PGTT_F_ACCEL + i - 3];
-    else if (i < 9) v = sh_fr[PGTT_F_GLOBAL_ANGVEL + i - 6];
-    else if (i < 21) v = sh_fr[PGTT_F_ACT_FORCE + i - 9];
-    else if (i < 25) v = sel4(i - 21, last_contact[0], last_contact[1], last_contact[2], last_contact[3]);
-    else if (i < 37) v = sh_fr[PGTT_F_FEET_VEL + i - 25];
-    else if (i < 41) v = sel4(i - 37, air[0], air[1], air[2], air[3]);
-    else v = 0.f;
-    sh_obs[OBSD + OBSD + i] = v;
-  }
+  if (lane < PGTT_PRIV - PGTT_OBS) sh_obs[OBSD + OBSD + lane] = *reinterpret_cast<const float*>(srcb + psrc);
   // history buffers (joystick_pgtt.py:319-334): motor_targets in sh_st was written by the physics kernel
   float hist_q = 0.f, hist_v = 0.f; const bool upd = (step_ctr % cfg->history_update_steps) == 0;
   if (lane < 24) {
