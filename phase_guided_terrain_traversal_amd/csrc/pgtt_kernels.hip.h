@@ -606,7 +606,7 @@ enum { OL_ST = 0, OL_FR = OL_ST + PGTT_NSTATE, OL_SCAN = OL_FR + PGTT_NFRAME, OL
        OD_PHASE = 0 /* cos x4, sin x4 */, OD_GAIT = 8, OD_CMD = 9, OD_ZERO = 12, OD_LASTC = 13, OD_AIR = 17,
        OD_SCALE = 21 /* 0, gyro, gravity, joint pos, joint vel, scan */, OD_OFFS = 27 /* 0, key_qpos[7..18] */, OD_END = 40, OL_END = OL_DRV + OD_END };
 constexpr int kObsRowSlots = 192, kPrivSlots = 64;
-struct ObsRowTab { unsigned row[2][kObsRowSlots]; unsigned short priv[kPrivSlots]; };
+struct ObsRowTab { unsigned row[2][kObsRowSlots]; unsigned short priv[kPrivSlots]; unsigned short quad[64][4]; };
 // descriptor: bits 0..10 byte offset of the source, 11..20 byte offset of the noise word in sh_rng, 21..25 byte offset of the scale in
 // OD_SCALE (20 = scan: the row is taken relative to zmin), 26..31 byte offset of the offset in OD_OFFS
 constexpr unsigned obs_row_desc(int i) {       // i = row in the PGTT layout (joystick_pgtt.py:336-349)
@@ -634,8 +634,19 @@ constexpr unsigned short obs_priv_src(int i) {    // the 44 privileged extras (j
   else if (i < 41) src = OL_DRV + OD_AIR + i - 37;
   return (unsigned short)(src * 4);
 }
+// Quadrant statistics (joystick_pgtt.py:169-190, n = 6 on both axes of the 13 x 9 grid: top / back = rows 0..5 / 7..12, right / left =
+// columns 7..8 / 0..5): the 16 lanes of row q of the wave cover quadrant q (0 top right, 1 top left, 2 back right, 3 back left), three
+// cells each; a quadrant has 12 or 36 cells, the surplus slots repeat cells of the same quadrant (max and min do not mind).
+constexpr unsigned short obs_quad_cell(int lane, int j) {
+  const int q = lane >> 4, s = (lane & 15) + 16 * j;
+  const bool left = (q & 1) != 0, back = (q & 2) != 0;
+  const int ncol = left ? 6 : 2, ncell = 6 * ncol, k = s % ncell;
+  const int r = (back ? 7 : 0) + k / ncol, c = (left ? 0 : 7) + k % ncol;
+  return (unsigned short)((OL_SCAN + r * PGTT_SCAN_W + c) * 4);
+}
 constexpr ObsRowTab make_obs_row_tab() {
   ObsRowTab t{};
+  for (int l = 0; l < 64; l++) for (int j = 0; j < 4; j++) t.quad[l][j] = obs_quad_cell(l, j < 3 ? j : 0);
   for (int io = 0; io < kObsRowSlots; io++) {
     t.row[0][io] = obs_row_desc(io);
     // the baseline layout (go2/joystick.py) drops rows 30..37 (phase) and 38 + NSCAN (gait_freq)
@@ -713,6 +724,7 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
 #pragma unroll
   for (int it = 0; it < 3; it++) rdesc[it] = kObsRowTab.row[baseline ? 1 : 0][lane + 64 * it];
   psrc = kObsRowTab.priv[lane];
+  const uint2 qcell = *reinterpret_cast<const uint2*>(kObsRowTab.quad[lane]);      // byte offsets of this lane's three scan cells
   // the running sums this step adds to (rows of this env, touched by this wave only) are requested here, a launch ahead of their use:
   // at the end of the wave nothing is left to hide a round trip behind
   float epm_old = 0.f, ivs_old = 0.f;
@@ -870,20 +882,18 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
   // ---------------- quadrant statistics (joystick_pgtt.py:169-190): n = 6 on both axes of the 13x9 grid
   float qmax[4], qmin[4];
   {
-    const int n = (PGTT_SCAN_H - 1) / 2;
-    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    __syncthreads();                     // the scan is in LDS
+    const char* const srcb = reinterpret_cast<const char*>(sh_src);
+    const float c0 = *reinterpret_cast<const float*>(srcb + (qcell.x & 0xffffu)), c1 = *reinterpret_cast<const float*>(srcb + (qcell.x >> 16)),
+                c2 = *reinterpret_cast<const float*>(srcb + (qcell.y & 0xffffu));
+    float mx = fmaxf(fmaxf(c0, c1), c2), mn = fminf(fminf(c0, c1), c2);
+    mx = fmaxf(mx, dpp_f<0xB1>(mx)); mx = fmaxf(mx, dpp_f<0x4E>(mx)); mx = fmaxf(mx, dpp_f<0x124>(mx)); mx = fmaxf(mx, dpp_f<0x128>(mx));
+    mn = fminf(mn, dpp_f<0xB1>(mn)); mn = fminf(mn, dpp_f<0x4E>(mn)); mn = fminf(mn, dpp_f<0x124>(mn)); mn = fminf(mn, dpp_f<0x128>(mn));
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      int idx = lane + 64 * h;
-      if (idx >= PGTT_NSCAN) continue;
-      int r = idx / PGTT_SCAN_W, c = idx - r * PGTT_SCAN_W;
-      bool top = r < n, back = r >= n + 1, left = c < n, right = c >= n + 1;
-      int qd = (top && right) ? 0 : ((top && left) ? 1 : ((back && right) ? 2 : ((back && left) ? 3 : -1)));
-#pragma unroll
-      for (int k = 0; k < 4; k++) if (qd == k) { mx[k] = fmaxf(mx[k], z[h]); mn[k] = fminf(mn[k], z[h]); }
+    for (int k = 0; k < 4; k++) {
+      qmax[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx), 16 * k));
+      qmin[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mn), 16 * k));
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++) { qmax[k] = wave_max(mx[k]); qmin[k] = wave_min(mn[k]); }
   }
   const float zmin = wave_min(fminf(z[0], v1 ? z[1] : INFINITY));
 
