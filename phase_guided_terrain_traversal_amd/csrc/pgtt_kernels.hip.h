@@ -480,11 +480,13 @@ PG_INL void task_rewards(const float* sh_st, const float* sh_fr, const float* sh
     done = sh_fr[PGTT_F_UPVECTOR + 2] < 0.f;
     float rew[PGTT_NREW];
     const float cmd_norm = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1] + cmd[2] * cmd[2]);
+    // the three exponentials (both tracking terms, feet_phase): WAVE = true evaluates them in ONE expf expansion, lanes 0 / 1 / 2
+    float xlin, xang;
     {
       float e0 = cmd[0] - sh_fr[PGTT_F_LOCAL_LINVEL], e1 = cmd[1] - sh_fr[PGTT_F_LOCAL_LINVEL + 1];
-      rew[PGTT_R_TRACKING_LIN_VEL] = expf(-(e0 * e0 + e1 * e1) / cfg->tracking_sigma);
+      xlin = -(e0 * e0 + e1 * e1) / cfg->tracking_sigma;
       float ea = cmd[2] - sh_fr[PGTT_F_GYRO + 2];
-      rew[PGTT_R_TRACKING_ANG_VEL] = expf(-(ea * ea) / cfg->tracking_sigma);
+      xang = -(ea * ea) / cfg->tracking_sigma;
     }
     rew[PGTT_R_LIN_VEL_Z] = sh_fr[PGTT_F_GLOBAL_LINVEL + 2] * sh_fr[PGTT_F_GLOBAL_LINVEL + 2];
     rew[PGTT_R_ANG_VEL_XY] = sh_fr[PGTT_F_GLOBAL_ANGVEL] * sh_fr[PGTT_F_GLOBAL_ANGVEL] + sh_fr[PGTT_F_GLOBAL_ANGVEL + 1] * sh_fr[PGTT_F_GLOBAL_ANGVEL + 1];
@@ -549,7 +551,17 @@ PG_INL void task_rewards(const float* sh_st, const float* sh_fr, const float* sh
       }
       float moving = cmd_norm > 0.01f ? 1.f : 0.f;
       rew[PGTT_R_FEET_SLIP] = slip * moving; rew[PGTT_R_FEET_CLEARANCE] = clear;
-      rew[PGTT_R_FEET_PHASE] = expf(-perr / cfg->phase_sigma); rew[PGTT_R_FEET_SWING] = swing;
+      const float xph = -perr / cfg->phase_sigma;
+      if constexpr (WAVE) {
+        const int ln = (int)(threadIdx.x & 63);
+        const int ex = __float_as_int(expf(ln == 0 ? xlin : (ln == 1 ? xang : xph)));
+        rew[PGTT_R_TRACKING_LIN_VEL] = __int_as_float(__builtin_amdgcn_readlane(ex, 0));
+        rew[PGTT_R_TRACKING_ANG_VEL] = __int_as_float(__builtin_amdgcn_readlane(ex, 1));
+        rew[PGTT_R_FEET_PHASE] = __int_as_float(__builtin_amdgcn_readlane(ex, 2));
+      } else {
+        rew[PGTT_R_TRACKING_LIN_VEL] = expf(xlin); rew[PGTT_R_TRACKING_ANG_VEL] = expf(xang); rew[PGTT_R_FEET_PHASE] = expf(xph);
+      }
+      rew[PGTT_R_FEET_SWING] = swing;
       rew[PGTT_R_FEET_AIR_TIME] = airr * moving; rew[PGTT_R_CONTACT] = -con; rew[PGTT_R_CENTER] = center;
       rew[PGTT_R_FEET_HEIGHT] = fh * moving;
       float bh = sh_st[PGTT_S_QPOS + 2] - minfoot - 0.27f;
@@ -748,7 +760,18 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
   } else {
     yaw = 0.f;
   }
-  float sy, cy; sincosf(yaw, &sy, &cy);
+  // ONE sincos evaluation for the yaw (lanes 8..63; every lane then takes it from lane 8) and for the eight phase rows of the observation
+  // (lanes 0..7: cos x4, sin x4 of the phases the step starts with - parked in LDS until the rows are formed): the expansion is ~80 vector
+  // instructions whatever the number of lanes that want it
+  float sy, cy;
+  if (OMODE == OBS_SCAN_ONLY || OMODE == OBS_SCAN_LIFT) sincosf(yaw, &sy, &cy);
+  else {
+    const int f = lane & 3;
+    const float ph = OMODE == OBS_RESET ? ((f == 1 || f == 2) ? (float)M_PI : 0.f) : sh_st[PGTT_S_PHASE + f];
+    float sn, cs; sincosf(lane < 8 ? ph : yaw, &sn, &cs);
+    if (lane < 8) sh_drv[OD_PHASE + lane] = lane < 4 ? cs : sn;
+    sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 8)); cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 8));
+  }
   const float oz = bz + cfg->scan_z_offset;
   V3 org[2]; float hit[2];
 #pragma unroll
@@ -961,12 +984,7 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
     philox4x32_10((unsigned)a.seed, (unsigned)(a.seed >> 32), c0, c1, c2, c3);
     sh_rng[4 * lane + 0] = c0; sh_rng[4 * lane + 1] = c1; sh_rng[4 * lane + 2] = c2; sh_rng[4 * lane + 3] = c3;
   }
-  // the per-env scalars the rows draw on, next to the rows' other sources: phase rows (cos x4, sin x4: ONE sincos evaluation by eight lanes),
-  // gait frequency, command, last contact, air time, the five noise scales and the twelve joint offsets
-  if (!baseline && lane < 8) {      // the baseline observation has no phase rows
-    float sn, cs; sincosf(sel4(lane & 3, phase[0], phase[1], phase[2], phase[3]), &sn, &cs);
-    sh_drv[OD_PHASE + lane] = lane < 4 ? cs : sn;
-  }
+  // the per-env scalars the rows draw on, next to the rows' other sources (the phase rows are there since the yaw was formed): gait frequency, command, last contact, air time, the five noise scales and the twelve joint offsets
   if (lane < 12) sh_drv[OD_OFFS + 1 + lane] = m->key_qpos[7 + lane];
   if (lane == 0) {
     sh_drv[OD_GAIT] = gait_freq; sh_drv[OD_ZERO] = 0.f; sh_drv[OD_OFFS] = 0.f;
