@@ -270,6 +270,14 @@ int pgtt_physics(pgtt_handle h, const float* action_Nx12, void* stream);  /* 4 x
 int pgtt_observe(pgtt_handle h, const float* action_Nx12, void* stream);  /* scan + obs + rewards + bookkeeping */
 int pgtt_scan(pgtt_handle h, float yaw_override_or_nan, void* stream);     /* K11 alone -> scan_z */
 
+/* Interval reduction of the running sums the step kernels keep (PgttBuffers.interval_sums, [PGTT_NMETRIC + 2][N]: metrics, reward, done)
+ * into out_dev[PGTT_NMETRIC + 3]: entry k < PGTT_NMETRIC + 2 receives the sum over the envs of row k, the last entry `env_steps` (the
+ * caller's count of the env-steps the block holds, so that the PGTT_NMETRIC + 3 floats are ready for ONE all-reduce over the ranks);
+ * accumulate != 0 adds to out_dev instead of overwriting it.  The rows are cleared for the next interval.  One launch: the rank-local
+ * half of the logging reduction (the reference averages its metrics over the batch inside the jitted epoch,
+ * training/train.py:142-161).  PGTT_E_STATE when no interval_sums buffer is bound. */
+int pgtt_interval_reduce(pgtt_handle h, float* out_dev, float env_steps, int accumulate, void* stream);
+
 /* TEST HOOKS (refused with PGTT_E_STATE unless the handle was created with PgttConfig.test_hooks != 0; tests/test_gpu_golden.py): the reference-generated fixtures of Joystick.step / Joystick.reset
  * (go2/joystick_pgtt.py:50-131,141-231 executed with jax.random stubbed and fake physics outputs) can only be replayed when every
  * uniform draw returns a fixed value (rng_value; NaN = the Philox streams) and when the step takes the 117 scan heights from

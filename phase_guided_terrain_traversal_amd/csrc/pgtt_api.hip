@@ -364,6 +364,16 @@ int pgtt_scan(pgtt_handle h, float yaw_override_or_nan, void* stream) {
   return PGTT_OK;
 }
 
+int pgtt_interval_reduce(pgtt_handle h, float* acc_dev, float env_steps, int accumulate, void* stream) {
+  if (int rc = check_ready(h)) return rc;
+  if (!acc_dev) return fail(PGTT_E_ARG, "pgtt_interval_reduce: null output");
+  if (!h->buf.interval_sums) return fail(PGTT_E_STATE, "pgtt_interval_reduce: no interval_sums buffer is bound");
+  HIP_TRY(hipSetDevice(h->device));
+  hipLaunchKernelGGL(pgtt::interval_reduce_kernel<0>, dim3(PGTT_NMETRIC + 3), dim3(256), 0, (hipStream_t)stream, h->buf.interval_sums, h->N, PGTT_NMETRIC + 2, acc_dev, env_steps, accumulate);
+  HIP_TRY(hipGetLastError());
+  return PGTT_OK;
+}
+
 int pgtt_set_test_overrides(pgtt_handle h, float rng_value_or_nan, int scan_preset) {
   if (!h) return fail(PGTT_E_ARG, "null handle");
   if (!h->cfg.test_hooks) return fail(PGTT_E_STATE, "pgtt_set_test_overrides: the handle was not created with PgttConfig.test_hooks");

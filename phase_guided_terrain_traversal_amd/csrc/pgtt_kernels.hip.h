@@ -1144,6 +1144,32 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
 }
 
 
+// ------------------------------------------------------------------ interval reduction: one block per row of interval_sums
+// out[k] (+)= sum over the envs of row k, and the row is cleared: read, zero and reduce in one pass (a GEMV, a fill and an add otherwise);
+// block `rows` only hands the caller's env-step count over
+template <int UNUSED>
+__global__ __launch_bounds__(256) void interval_reduce_kernel(float* __restrict__ sums, int N, int rows, float* __restrict__ acc, float env_steps, int accumulate) {
+  if ((int)blockIdx.x == rows) { if (threadIdx.x == 0) acc[rows] = (accumulate ? acc[rows] : 0.f) + env_steps; return; }
+  float* __restrict__ row = sums + (long)blockIdx.x * N;
+  float s = 0.f;
+  if ((N & 3) == 0) {
+    float4* __restrict__ row4 = reinterpret_cast<float4*>(row);
+    for (int i = threadIdx.x; i < (N >> 2); i += 256) { const float4 v = row4[i]; row4[i] = make_float4(0.f, 0.f, 0.f, 0.f); s += (v.x + v.y) + (v.z + v.w); }
+  } else {
+    for (int i = threadIdx.x; i < N; i += 256) { s += row[i]; row[i] = 0.f; }
+  }
+  s = row16_sum(s);                                      // the 16 lanes of a DPP row, then the rows and the waves through LDS
+  __shared__ float part[16];
+  if ((threadIdx.x & 15) == 0) part[threadIdx.x >> 4] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) t += part[i];
+    acc[blockIdx.x] = (accumulate ? acc[blockIdx.x] : 0.f) + t;
+  }
+}
+
 // ------------------------------------------------------------------ task: one env per LANE (coalesced SoA rows)
 // The per-env scalar half of a control step: contact bookkeeping, the 21 rewards, termination, command resampling,
 // history buffers, Episode / AutoReset wrapper semantics.  In the fused observe kernel every wave repeats this ~2.5 k

@@ -51,6 +51,22 @@ def init_from_env(backend: Optional[str] = None, force: bool = False) -> Tuple[i
     return rank, local, world
 
 
+class _Reduced(dict):
+    """result of a reduction: the all-reduced sums; the means are formed when somebody asks for them (a logging step, not every interval)"""
+
+    def __missing__(self, key):
+        buf = self["sums"]
+        n = buf[abi.NMETRIC + 2].clamp(min=1.0)
+        if key == "metrics_mean":
+            v = buf[:abi.NMETRIC] / n
+        elif key == "reward_mean":
+            v = buf[abi.NMETRIC] / n
+        else:
+            raise KeyError(key)
+        self[key] = v
+        return v
+
+
 class MetricReducer:
     """Fused all-reduce of [22 metric sums, sum_reward, n_done, n_envs] (= 25 floats)."""
 
@@ -60,10 +76,12 @@ class MetricReducer:
         self.device = device
         self.acc = torch.zeros(self.SIZE, dtype=torch.float32, device=device)
         self.count = 0.0          # env-steps accumulated since the last reduce (kept on the host: no kernel per step)
+        self._dirty = False       # the accumulator holds contributions since the last reduce
         self._ones = None
 
     def accumulate(self, metrics: torch.Tensor, reward: torch.Tensor, done: torch.Tensor) -> None:
         """metrics [22, N], reward [N], done [N] of one step (local shard)."""
+        self._dirty = True
         self.acc[:abi.NMETRIC] += metrics.sum(dim=1)
         self.acc[abi.NMETRIC] += reward.sum()
         self.acc[abi.NMETRIC + 1] += done.sum()
@@ -75,6 +93,7 @@ class MetricReducer:
         n = block.shape[1]
         if self._ones is None or self._ones.shape[0] != n:
             self._ones = torch.ones(n, dtype=torch.float32, device=block.device)
+        self._dirty = True
         self.acc[:abi.NMETRIC + 2].addmv_(block, self._ones)
         self.count += float(n)
 
@@ -84,10 +103,24 @@ class MetricReducer:
         n = sums.shape[1]
         if self._ones is None or self._ones.shape[0] != n:
             self._ones = torch.ones(n, dtype=torch.float32, device=sums.device)
+        self._dirty = True
         self.acc[:abi.NMETRIC + 2].addmv_(sums, self._ones)
         sums.zero_()
         self.count += float(env_steps)
         return self.reduce()
+
+    def reduce_env(self, env, env_steps: float) -> Dict[str, torch.Tensor]:
+        """reduce_block for a `Joystick` that keeps interval sums: the sum over the envs, the clearing of the block and the accumulation
+        are ONE launch of libpgtt (pgtt_interval_reduce) instead of a GEMV, a fill and an add; then the fused all-reduce."""
+        if self._dirty or self.count != 0.0:                   # per-step contributions are waiting in the accumulator: the general path
+            env.interval_reduce(self.acc, 0.0, accumulate=True)
+            self.count += float(env_steps)
+            return self.reduce()
+        buf = torch.empty(self.SIZE, dtype=torch.float32, device=self.acc.device)
+        env.interval_reduce(buf, float(env_steps))
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        return _Reduced(sums=buf, done_count=buf[abi.NMETRIC + 1], env_steps=buf[abi.NMETRIC + 2])
 
     def reduce(self) -> Dict[str, torch.Tensor]:
         """Sum over ranks (one RCCL all-reduce), reset the local accumulator, return global means."""
@@ -97,6 +130,7 @@ class MetricReducer:
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         self.acc.zero_()
+        self._dirty = False
         n = buf[abi.NMETRIC + 2].clamp(min=1.0)
         return {"metrics_mean": buf[:abi.NMETRIC] / n, "reward_mean": buf[abi.NMETRIC] / n,
                 "done_count": buf[abi.NMETRIC + 1], "env_steps": buf[abi.NMETRIC + 2]}

@@ -173,6 +173,12 @@ class Joystick:
         native.check(self._lib.pgtt_scan(self._h, float("nan") if yaw is None else float(yaw), self._stream()))
         return self.buffers["scan_z"]
 
+    def interval_reduce(self, out: torch.Tensor, env_steps: float = 0.0, accumulate: bool = False) -> None:
+        """out[k] (+)= sum over the envs of buffers['interval_sums'][k] (k < NMETRIC + 2), out[NMETRIC + 2] (+)= env_steps, the rows cleared:
+        one launch (pgtt_interval_reduce)"""
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == abi.NMETRIC + 3 and out.device == self.buffers["interval_sums"].device
+        native.check(self._lib.pgtt_interval_reduce(self._h, out.data_ptr(), float(env_steps), int(accumulate), self._stream()))
+
     def set_test_overrides(self, rng_value: Optional[float] = None, scan_preset: bool = False) -> None:
         """test hooks of libpgtt (include/pgtt.h): fixed uniform draws / scan heights taken from buffers['scan_z']"""
         native.check(self._lib.pgtt_set_test_overrides(self._h, float("nan") if rng_value is None else float(rng_value), int(scan_preset)))

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PGTT_LIB", os.path.join(_HERE, "libpgtt.so"))   # PGT
 _LIB: Optional[C.CDLL] = None
 
 EXPORTS = ["pgtt_create", "pgtt_destroy", "pgtt_set_terrain", "pgtt_bind", "pgtt_reset", "pgtt_step",
-           "pgtt_physics", "pgtt_observe", "pgtt_scan", "pgtt_set_test_overrides", "pgtt_enable_timing", "pgtt_last_kernel_ms", "pgtt_kernel_ms_mean",
+           "pgtt_physics", "pgtt_observe", "pgtt_scan", "pgtt_interval_reduce", "pgtt_set_test_overrides", "pgtt_enable_timing", "pgtt_last_kernel_ms", "pgtt_kernel_ms_mean",
            "pgtt_obs_dims", "pgtt_sizeof_model", "pgtt_sizeof_config", "pgtt_sizeof_buffers", "pgtt_version", "pgtt_last_error"]
 TRAIN_EXPORTS = ["pgtt_ppo_policy_loss", "pgtt_ppo_linear_backward"]      # include/pgtt_train.h: trainer helpers, not the env boundary
 
@@ -42,6 +42,7 @@ def lib() -> C.CDLL:
         for fn in ("pgtt_step", "pgtt_physics", "pgtt_observe"):
             getattr(L, fn).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.pgtt_scan.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
+        L.pgtt_interval_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
         L.pgtt_enable_timing.argtypes = [C.c_void_p, C.c_int]
         L.pgtt_set_test_overrides.argtypes = [C.c_void_p, C.c_float, C.c_int]
         L.pgtt_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]

@@ -324,10 +324,37 @@ def test_interval_sums_equal_the_per_step_sums(observe):
     torch.cuda.synchronize()
     assert torch.equal(env.buffers["interval_sums"], ref) and float(ref[abi.NMETRIC + 1].sum()) > 0
     from phase_guided_terrain_traversal_amd.distributed import MetricReducer
+    # the rank-local reduction as ONE launch of the library (pgtt_interval_reduce: sum over the envs, block cleared, accumulator added to)
+    # against the torch form of the same reduction (GEMV + fill), on a copy of the block; a ragged env count takes the scalar loop
+    want = ref.double().sum(1)
+    acc = torch.full((abi.NMETRIC + 3,), 2.0, dtype=torch.float32, device="cuda")
+    env.interval_reduce(acc, 7.0, accumulate=True)
+    torch.cuda.synchronize()
+    assert float(env.buffers["interval_sums"].abs().sum()) == 0.0 and float(acc[abi.NMETRIC + 2]) == 9.0
+    assert torch.allclose(acc[:abi.NMETRIC + 2].double() - 2.0, want, rtol=2e-5, atol=1e-3)
+    env.buffers["interval_sums"].copy_(ref)
+    env.interval_reduce(acc, 5.0)                                  # overwrite form
+    assert float(acc[abi.NMETRIC + 2]) == 5.0 and torch.allclose(acc[:abi.NMETRIC + 2].double(), want, rtol=2e-5, atol=1e-3)
+    env.buffers["interval_sums"].copy_(ref)
     out = MetricReducer(torch.device("cuda", 0)).reduce_block(env.buffers["interval_sums"], 25.0 * 1024)
     assert float(env.buffers["interval_sums"].abs().sum()) == 0.0 and float(out["env_steps"]) == 25 * 1024
     assert abs(float(out["reward_mean"]) - float(ref[abi.NMETRIC].sum()) / (25 * 1024)) < 1e-6
+    env.buffers["interval_sums"].copy_(ref)
+    out2 = MetricReducer(torch.device("cuda", 0)).reduce_env(env, 25.0 * 1024)
+    assert float(env.buffers["interval_sums"].abs().sum()) == 0.0 and float(out2["env_steps"]) == 25 * 1024
+    assert torch.allclose(out2["metrics_mean"], out["metrics_mean"], rtol=2e-5, atol=1e-6) and abs(float(out2["reward_mean"]) - float(out["reward_mean"])) < 1e-6
     env.close()
+    if observe == "fused":
+        env, _, _ = make(n=1001, level="level13", interval_sums=True)
+        env.reset(seed=2)
+        for k in range(3):
+            env.step(actions(k, 1001))
+        want = env.buffers["interval_sums"].double().sum(1)
+        acc = torch.zeros(abi.NMETRIC + 3, dtype=torch.float32, device="cuda")
+        env.interval_reduce(acc, 3.0 * 1001)
+        assert float(env.buffers["interval_sums"].abs().sum()) == 0.0 and torch.allclose(acc[:abi.NMETRIC + 2].double(), want, rtol=2e-5, atol=1e-3)
+        assert float(acc[abi.NMETRIC + 2]) == 3003.0
+        env.close()
 
 
 def test_configs4_one_rank_of_the_curriculum_shard():
