@@ -298,7 +298,8 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
 #endif
   if (!valid) return;
 #ifdef PGTT_EFFORT
-  if (a.buf.dbg_contact) { a.buf.dbg_contact[(long)e * 16 + 14] = (int)(unsigned)s.eff; a.buf.dbg_contact[(long)e * 16 + 15] = (int)(unsigned)(s.eff >> 32); }
+  if (a.buf.dbg_contact) { a.buf.dbg_contact[(long)e * 16 + 14] = (int)(unsigned)s.eff; a.buf.dbg_contact[(long)e * 16 + 15] = (int)(unsigned)(s.eff >> 32);
+    a.buf.dbg_contact[(long)e * 16 + 12] = s.eff_hess; a.buf.dbg_contact[(long)e * 16 + 13] = s.eff_hess_same; }       // the same for every env of the wave
 #endif
   // The compiler would otherwise keep the ~50 row addresses formed for the loads at the top alive (spilled to scratch)
   // until these stores: an opaque copy of the env index makes it re-form them here (one mad each).

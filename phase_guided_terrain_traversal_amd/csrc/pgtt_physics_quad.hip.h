@@ -225,6 +225,8 @@ struct QSim {
 #ifdef PGTT_EFFORT
   // -DPGTT_EFFORT builds (tools/gpu_effort.py): 1 + the line-search rounds THIS env needed, 3 bits per Newton trip, 5 trips per substep
   unsigned long long eff = 0ull; int eff_pos = 0, eff_sub = 0;
+  // ... and how often the Hessian is rebuilt although NO lane of the wave has a row that changed sides since the last Newton trip
+  unsigned eff_pat = 0xffffffffu; int eff_hess = 0, eff_hess_same = 0;
 #endif
   bool pen_overflow;         // some substep of this call met more than kMaxPenQ simultaneously penetrating boxes under this foot (collide())
 };
@@ -1264,6 +1266,21 @@ struct QSolver {
   }
 
   PG_INL void update_gradient() {
+#ifdef PGTT_EFFORT
+    {
+      unsigned pat = 0u;
+#pragma unroll
+      for (int k = 0; k < 3; k++) pat |= (jar_lim[k] < 0.f ? 1u : 0u) << k;
+#pragma unroll
+      for (int r = 0; r < 4; r++) pat |= (jar0[r] < 0.f ? 1u : 0u) << (3 + r);
+      if (kSubs == 4) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) pat |= ((own_on((int)(threadIdx.x & 3)) && mjar[r] < 0.f) ? 1u : 0u) << (7 + r);
+      }
+      s.eff_hess += 1; s.eff_hess_same += __ballot(pat != s.eff_pat) == 0ull ? 1 : 0;
+      s.eff_pat = pat;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < 6; i++) gb[i] = Mab[i] - s.qfs_b[i] - fcb[i];
 #pragma unroll
@@ -1689,7 +1706,7 @@ struct QSolver {
 
   PG_INL void solve() {
 #ifdef PGTT_EFFORT
-    s.eff_pos = 15 * s.eff_sub; s.eff_sub++;
+    s.eff_pos = 15 * s.eff_sub; s.eff_sub++; s.eff_pat = 0xffffffffu;
 #endif
     int nb = 0;
 #pragma unroll

@@ -20,13 +20,14 @@ env = Joystick("flat_terrain" if wl == "flat" else "stairs", configs.training_co
 env.reset(seed=1)
 g = torch.Generator(device="cuda").manual_seed(0)
 pool = [torch.tanh(torch.randn(n, 12, generator=g, device="cuda") * 0.6) for _ in range(32)]
-rec = []
+rec = []; hess = []
 for k in range(steps):
     env.step(pool[k % 32])
     dc = env.buffers["dbg_contact"].cpu().numpy().reshape(n, 16)
     eff = dc[:, 14].astype(np.uint32).astype(np.uint64) | (dc[:, 15].astype(np.uint32).astype(np.uint64) << np.uint64(32))
     need = np.stack([(eff >> np.uint64(3 * i)) & np.uint64(7) for i in range(20)], 1).astype(np.int64)     # [env][substep * 5 + trip]: 0 = not in the trip, else 1 + rounds
     rec.append(need)
+    hess.append(dc[::G, 12:14].astype(np.int64))          # per wave: Hessian builds, of which with no row of any lane having changed sides
 rec = np.stack(rec)[50:]                                   # past the reset transient
 def cost(need, order):
     w = need[order].reshape(n // G, G, 20)
@@ -47,3 +48,8 @@ for k in ("fixed", "sorted", "oracle"):
     print(f"  {k:7s}: solver ticks of the mean wave {np.mean(tot[k + '_mean']):9.0f}   of the slowest wave {np.mean(tot[k]):9.0f}")
 a, b = own(rec[1:].reshape(-1, 20)).reshape(len(rec) - 1, n), own(rec[:-1].reshape(-1, 20)).reshape(len(rec) - 1, n)
 print(f"  correlation of an env's solver work with its previous step's: {np.corrcoef(a.ravel(), b.ravel())[0, 1]:.3f}")
+hess = np.stack(hess)[51:]
+wcost = np.stack([cost(rec[t], np.arange(n))[0] for t in range(1, len(rec))])
+slow = wcost >= np.percentile(wcost, 99, axis=1, keepdims=True)
+print(f"  Hessian builds per wave and control step {hess[..., 0].mean():.2f}, of which with NO row of the wave on a new side since the last trip: "
+      f"{hess[..., 1].mean():.2f} (all waves), {hess[..., 1][slow].mean():.2f} of {hess[..., 0][slow].mean():.2f} (the slowest 1 % of each step)")
