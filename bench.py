@@ -202,6 +202,14 @@ def timed_window(env, n, steps, warmup, dev, rank, world, stub, sync):
             flush(0)
         e1.record(); sync()
         gemv_ms = e0.elapsed_time(e1) / 8 / REDUCE_EVERY
+    # the exact sequence that stands between the warm-up steps and the clock, once, here: the first use of a torch op loads its code object
+    # (~50 ms of host time each; a kernel trace of the driver's command showed the device idle for 100 ms right before the timed window
+    # - and physics_kernel at 175 us instead of 166 us inside it, the clocks having dropped)
+    sums.zero_(); reducer.reduce(); env_steps_seen.zero_()
+    env.enable_timing(8)
+    if world > 1:
+        dist.barrier()
+    sync()
     # ---- prime 2 + the W untimed warm-up steps of the contract, back to back: the device enters the timed window the way it runs a
     # roll-out - busy.  A gap of host-bound work here (event read-back, the eight timed reductions above) used to let it clock down just
     # before the clock started: a 20-step window then read physics_kernel at 180 us against 168 us in the 300-step window.
