@@ -284,7 +284,7 @@ int pgtt_interval_reduce(pgtt_handle h, float* out_dev, float env_steps, int acc
  * buf.scan_z instead of casting rays (scan_preset != 0). */
 int pgtt_set_test_overrides(pgtt_handle h, float rng_value_or_nan, int scan_preset);
 
-/* enable = 0 off, 1 time every step, n > 1 time every n-th step (an event record costs a few us of GPU idle).
+/* enable = 0 off, 1 time every step, n > 1 time every n-th step, starting with step n / 2 (an event record costs a few us of GPU idle).
  * time of the most recent physics / observe kernels, measured with HIP events on `stream`
  * (valid after the stream is synchronised; used by bench.py for the roofline figure). */
 int pgtt_enable_timing(pgtt_handle h, int enable);

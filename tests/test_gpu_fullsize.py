@@ -175,7 +175,7 @@ def test_kernel_timing_api():
     for k in range(33):
         env.step(actions(k, 512))
     pm, om, cnt = env.kernel_ms_mean()
-    assert cnt == 5 and pm > 0.0                # steps 0, 8, 16, 24, 32
+    assert cnt == 4 and pm > 0.0                # steps 4, 12, 20, 28 (mid-period: never the first step after a synchronisation)
     env.enable_timing(False)
     env.step(actions(0, 512))
     with pytest.raises(Exception):
