@@ -599,7 +599,7 @@ PG_INL void task_rewards(const float* sh_st, const float* sh_fr, const float* sh
 #ifdef PGTT_TIME
 // -DPGTT_TIME=<env> builds (tools/gpu_observe_time.py): phase ticks of the observe wave of that env at a.trace[60000 + i]
 #define PG_OTICK(i) do { if (OMODE == OBS_STEP && a.trace) { long long t_ = __builtin_readcyclecounter(); if (lane == 0) { if (e == PGTT_TIME) a.trace[60000 + (i)] = (float)(t_ - ot0_); \
-    if (blockIdx.x < 4096) a.trace[65536 + 8 * blockIdx.x + (i)] = (float)(t_ - ot0_); } } } while (0)        /* [65536 + 8 block + i]: every wave's boundaries */
+    if (blockIdx.x < 512) a.trace[61000 + 8 * blockIdx.x + (i)] = (float)(t_ - ot0_); } } } while (0)        /* [61000 + 8 block + i]: the boundaries of the first 512 waves (inside trace segment 0, clear of the physics records) */
 #elif defined(PGTT_OBS_STOP)
 // -DPGTT_OBS_STOP builds (tools/gpu_observe_instr.py): the step's observe wave leaves at phase boundary i when the test-hook integer says so
 #define PG_OTICK(i) do { if (OMODE == OBS_STEP && a.scan_preset == 100 + (i)) return; } while (0)

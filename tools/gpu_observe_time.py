@@ -25,8 +25,8 @@ for k in range(60):
 print(f"{wl}: observe wave of env 0, mean over {cnt} steps, total {acc.sum() / cnt:.0f} ticks")
 for nme, v in zip(names, acc / cnt):
     print(f"  {nme:34s} {v:9.0f} ticks  {100 * v / acc.sum() * cnt:5.1f} %")
-allw = np.diff(np.concatenate([np.zeros((4096, 1)), buf[65536:65536 + 8 * 4096].reshape(4096, 8).astype(np.float64)], 1), axis=1)
-print("last launch, all 4096 waves: ticks per phase, quantiles 10 / 50 / 90 / 100 %")
+allw = np.diff(np.concatenate([np.zeros((512, 1)), buf[61000:61000 + 8 * 512].reshape(512, 8).astype(np.float64)], 1), axis=1)
+print("last launch, the waves of blocks 0..511: ticks per phase, quantiles 10 / 50 / 90 / 100 %")
 for i, nme in enumerate(names):
     print(f"  {nme:34s}", " ".join(f"{q:7.0f}" for q in np.percentile(allw[:, i], [10, 50, 90, 100])))
 print(f"  {'whole wave':34s}", " ".join(f"{q:7.0f}" for q in np.percentile(allw.sum(1), [10, 50, 90, 100])))
