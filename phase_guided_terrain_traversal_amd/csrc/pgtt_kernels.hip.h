@@ -1073,6 +1073,18 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
   // env's state rows in their slots of the row image sh_st, the metrics with (reward, 1) behind them - and the wave then stores ROW RANGES
   // with one address per lane; picking "my row's value" out of registers costs a compare + select per candidate (22 for a metric) and a
   // 64-bit address per store site, in a kernel whose four waves per SIMD share the vector ALU.
+  // AutoReset of a finished episode: the first state and its observation are requested HERE, all at once (the copy loops at the end of the
+  // wave were eight dependent round trips - each store could alias the next load - and the few waves with a finished episode were the last
+  // of the launch to leave)
+  const bool restore = OMODE == OBS_STEP && cfg->autoreset && wdone && a.buf.first_state && a.buf.first_obs;
+  constexpr int kFirstObsPasses = (PGTT_OBS + PGTT_PRIV + 63) / 64;
+  float first_st = 0.f, first_ob[kFirstObsPasses];
+  if (restore) {
+    if (lane < PGTT_S_CMD) first_st = a.buf.first_state[lane * (long)N + e];
+    const float* __restrict__ fo = a.buf.first_obs + (long)e * (OBSD + PRIVD);
+#pragma unroll
+    for (int i = 0; i < kFirstObsPasses; i++) first_ob[i] = lane + 64 * i < OBSD + PRIVD ? fo[lane + 64 * i] : 0.f;
+  }
   __shared__ float sh_met[PGTT_NMETRIC + 2];
   __syncthreads();                       // the row image has been read for the last time (rewards, history)
   if (lane < 12) {
@@ -1120,16 +1132,15 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
   }
   if (OMODE == OBS_STEP && a.buf.interval_sums && lane < PGTT_NMETRIC + 2)
     a.buf.interval_sums[lane * (long)N + e] = ivs_old + (lane < PGTT_NMETRIC ? sh_met[lane] : (lane == PGTT_NMETRIC ? reward : (wdone ? 1.f : 0.f)));
-  const bool restore = OMODE == OBS_STEP && cfg->autoreset && wdone && a.buf.first_state && a.buf.first_obs;
-  if (restore) {
-    for (int r = lane; r < PGTT_S_CMD; r += 64) S[r * (long)N + e] = a.buf.first_state[r * (long)N + e];
-    const float* fo = a.buf.first_obs + (long)e * (OBSD + PRIVD);
-    for (int i = lane; i < OBSD; i += 64) a.buf.obs_state[(long)e * OBSD + i] = fo[i];
-    for (int i = lane; i < PRIVD; i += 64) a.buf.obs_priv[(long)e * PRIVD + i] = fo[OBSD + i];
-  } else {
-    for (int i = lane; i < OBSD; i += 64) a.buf.obs_state[(long)e * OBSD + i] = sh_obs[i];
-    for (int i = lane; i < PRIVD; i += 64) a.buf.obs_priv[(long)e * PRIVD + i] = sh_obs[OBSD + i];
+  if (restore) {                         // the first observation takes the place of this step's in LDS (same layout: state rows, then privileged rows)
+    static_assert(PGTT_S_CMD <= 64, "one lane per restored state row");
+    if (lane < PGTT_S_CMD) S[lane * (long)N + e] = first_st;
+#pragma unroll
+    for (int i = 0; i < kFirstObsPasses; i++) if (lane + 64 * i < OBSD + PRIVD) sh_obs[lane + 64 * i] = first_ob[i];
+    __syncthreads();
   }
+  for (int i = lane; i < OBSD; i += 64) a.buf.obs_state[(long)e * OBSD + i] = sh_obs[i];
+  for (int i = lane; i < PRIVD; i += 64) a.buf.obs_priv[(long)e * PRIVD + i] = sh_obs[OBSD + i];
   PG_OTICK(7);
 #ifdef PGTT_TIME
   if (OMODE == OBS_STEP && a.trace && lane == 0 && blockIdx.x < 4096) {      // placement and timeline of every observe wave

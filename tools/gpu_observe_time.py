@@ -30,6 +30,10 @@ print("last launch, the waves of blocks 0..511: ticks per phase, quantiles 10 / 
 for i, nme in enumerate(names):
     print(f"  {nme:34s}", " ".join(f"{q:7.0f}" for q in np.percentile(allw[:, i], [10, 50, 90, 100])))
 print(f"  {'whole wave':34s}", " ".join(f"{q:7.0f}" for q in np.percentile(allw.sum(1), [10, 50, 90, 100])))
+slow = np.argsort(allw.sum(1))[-8:]
+print("  the 8 slowest of them, ticks per phase:"); 
+for w in slow[::-1]:
+    print(f"    block {w:4d}: " + " ".join(f"{v:6.0f}" for v in allw[w]) + f"   sum {allw[w].sum():6.0f}")
 tw = buf[40960:40960 + 4 * 4096].view(np.uint32).reshape(-1, 4)
 tw = tw[tw[:, 3] != 0]
 hw, xcc, t0, t1 = tw[:, 0], tw[:, 1] & 0xF, tw[:, 2].astype(np.int64), tw[:, 3].astype(np.int64)
