@@ -42,6 +42,7 @@ struct pgtt_env {
   PgttConfig* d_cfg = nullptr;
   PgttModel* d_model = nullptr;
   pgtt::TerrainBox* d_terrain = nullptr;
+  float4* d_cull = nullptr;       // [T][B] (centre x, y, world-AABB half extents x, y): what the scan's cull reads, 16 of a record's 80 bytes, contiguous
   uint4* d_grid = nullptr; float grid_E = 1.f, grid_inv = 1.f;     // terrain grid of the collision pass (pgtt_physics_quad.hip.h::collide)
   int T = 0, B = 0;
   PgttBuffers buf{};
@@ -82,7 +83,7 @@ namespace {
 
 pgtt::KArgs make_args(pgtt_env* h, const unsigned char* mask, float yaw_override) {
   pgtt::KArgs a;
-  a.model = h->d_model; a.cfg = h->d_cfg; a.terrain = h->d_terrain; a.T = h->T; a.B = h->B; a.grid = h->d_grid; a.grid_E = h->grid_E; a.grid_inv = h->grid_inv;
+  a.model = h->d_model; a.cfg = h->d_cfg; a.terrain = h->d_terrain; a.cull = h->d_cull; a.T = h->T; a.B = h->B; a.grid = h->d_grid; a.grid_E = h->grid_E; a.grid_inv = h->grid_inv;
   a.buf = h->buf; a.N = h->N; a.seed = h->seed; a.env_off = h->env_off; a.mask = mask; a.yaw_override = yaw_override; a.write_qpos = 0;
   a.rng_fix = h->test_rng_fix; a.scan_preset = h->test_scan_preset;
   a.handover_w = h->d_handover; a.handover_r = nullptr;
@@ -206,6 +207,7 @@ int pgtt_destroy(pgtt_handle h) {
   if (h->d_model) hipFree(h->d_model);
   if (h->d_handover) hipFree(h->d_handover);
   if (h->d_terrain) hipFree(h->d_terrain);
+  if (h->d_cull) hipFree(h->d_cull);
   if (h->d_grid) hipFree(h->d_grid);
   for (int r = 0; r < pgtt_env::kRing; r++) for (int i = 0; i < 4; i++) if (h->ev[r][i]) hipEventDestroy(h->ev[r][i]);
   delete h;
@@ -218,6 +220,7 @@ int pgtt_set_terrain(pgtt_handle h, const float* boxes, int T, int B) {
   if (T > 0 && (!boxes || B == 0)) return fail(PGTT_E_ARG, "pgtt_set_terrain: null table");
   HIP_TRY(hipSetDevice(h->device));
   if (h->d_terrain) { HIP_TRY(hipFree(h->d_terrain)); h->d_terrain = nullptr; }
+  if (h->d_cull) { HIP_TRY(hipFree(h->d_cull)); h->d_cull = nullptr; }
   if (h->d_grid) { HIP_TRY(hipFree(h->d_grid)); h->d_grid = nullptr; }
   h->T = 0; h->B = 0;
   if (T == 0) return PGTT_OK;
@@ -275,6 +278,12 @@ int pgtt_set_terrain(pgtt_handle h, const float* boxes, int T, int B) {
   }
   HIP_TRY(hipMalloc(&h->d_terrain, tab.size() * sizeof(pgtt::TerrainBox)));
   HIP_TRY(hipMemcpy(h->d_terrain, tab.data(), tab.size() * sizeof(pgtt::TerrainBox), hipMemcpyHostToDevice));
+  {
+    std::vector<float4> cull(tab.size());
+    for (size_t i = 0; i < tab.size(); i++) cull[i] = make_float4(tab[i].px, tab[i].py, tab[i].hx, tab[i].hy);
+    HIP_TRY(hipMalloc(&h->d_cull, cull.size() * sizeof(float4)));
+    HIP_TRY(hipMemcpy(h->d_cull, cull.data(), cull.size() * sizeof(float4), hipMemcpyHostToDevice));
+  }
   h->T = T; h->B = B;
   return PGTT_OK;
 }

@@ -19,6 +19,7 @@ struct KArgs {
   const PgttModel* model;
   const PgttConfig* cfg;
   const TerrainBox* terrain;   // [T][B]
+  const float4* cull;          // [T][B] (px, py, hx, hy) of the same boxes: the scan's cull reads 1.6 KB per variant instead of strided pieces of 8 KB
   const uint4* grid;           // [T][kGridG * kGridG]: boxes whose grown world AABB touches the cell (bit b of the 128 = box b)
   float grid_E, grid_inv;      // the grid covers [-E, E]^2, cell (ix, iy) = floor((x + E) * inv), clamped
   int T, B;
@@ -690,19 +691,16 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
   __shared__ float sh_obs[PGTT_OBS + PGTT_PRIV + 2];
   __shared__ float sh_act[12];
 
-  // The terrain records of the env's variant do not depend on the state: lane j requests the first and the last 16 bytes of the
-  // 80-byte records of boxes j and j + 64 (centre, world-AABB half extents: what the cull needs) BEFORE the state rows are waited for,
-  // so the two round trips overlap - and the middle of a surviving record is then a cache hit
+  // The cull data of the env's variant do not depend on the state: lane j requests (centre x, y, world-AABB half extents x, y) of boxes j and
+  // j + 64 BEFORE the state rows are waited for, so the two round trips overlap.  They come from the compact table (16 contiguous bytes per
+  // box: 13 lines per variant) - the same four numbers out of the 80-byte records cost 160 line requests per wave, more than all its rows
   const TerrainBox* __restrict__ boxes = nullptr;
-  float4 brec[2][2];
+  float4 brec[2];
   if (HAS_TERRAIN) {
     const int v = a.buf.variant ? a.buf.variant[e] : 0;
     boxes = a.terrain + (long)v * a.B;
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int b = min(lane + 64 * h, a.B - 1);
-      brec[h][0] = reinterpret_cast<const float4*>(boxes + b)[0]; brec[h][1] = reinterpret_cast<const float4*>(boxes + b)[4];
-    }
+    for (int h = 0; h < 2; h++) brec[h] = a.cull[(long)v * a.B + min(lane + 64 * h, a.B - 1)];
   }
   if (OMODE == OBS_STEP && a.handover_r) {
     // this step's physics launch left qpos, qvel, the motor targets and the sensor frame env-major: two coalesced loads.  Of the other rows
@@ -809,10 +807,10 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
       const int b = lane + 64 * h;
       bool reach = false;
       if (b < a.B) {
-        const float4 A = brec[h][0], H = brec[h][1];
-        const float dx = A.x - bx, dy = A.y - by;
-        reach = (fabsf(dx) <= H.x + hx * acy + hy * asy) & (fabsf(dy) <= H.y + hx * asy + hy * acy) &
-                (fabsf(dx * cy + dy * sy) <= hx + H.x * acy + H.y * asy) & (fabsf(dy * cy - dx * sy) <= hy + H.x * asy + H.y * acy);
+        const float4 C = brec[h];            // centre x, y; world-AABB half extents x, y
+        const float dx = C.x - bx, dy = C.y - by;
+        reach = (fabsf(dx) <= C.z + hx * acy + hy * asy) & (fabsf(dy) <= C.w + hx * asy + hy * acy) &
+                (fabsf(dx * cy + dy * sy) <= hx + C.z * acy + C.w * asy) & (fabsf(dy * cy - dx * sy) <= hy + C.z * asy + C.w * acy);
       }
       const unsigned long long mk = __ballot(reach);
       const int slot = nsurv + __popcll(mk & ((1ull << lane) - 1ull));
@@ -822,7 +820,7 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
         // with relz = oz - pz the same for every ray of the env: the parameters of its two z faces and their validity are properties of the
         // BOX (`hz` below, the value ray_box_down's two-face form returns for a ray inside the footprint); a ray only decides "inside or not".
         // Such a box goes to LDS as the 9 numbers that test needs; any other box as its index (the loop reads its record from the table).
-        const float4 q0 = brec[h][0], q1 = reinterpret_cast<const float4*>(boxes + b)[1], q2 = reinterpret_cast<const float4*>(boxes + b)[2],
+        const float4 q0 = reinterpret_cast<const float4*>(boxes + b)[0], q1 = reinterpret_cast<const float4*>(boxes + b)[1], q2 = reinterpret_cast<const float4*>(boxes + b)[2],
                      q3 = reinterpret_cast<const float4*>(boxes + b)[3];
         const float m22 = q3.w;
         const bool fast = (q3.y == 0.f) & (q3.z == 0.f) & (m22 != 0.f) & (q2.y == 0.f) & (q3.x == 0.f);      // m20, m21, m22, m02, m12
