@@ -57,6 +57,33 @@ def test_determinism_and_shard_invariance():
         e.close()
 
 
+def test_step_equals_physics_then_observe_and_sees_caller_edits():
+    """pgtt_step hands the physics outputs to its observe launch through the library's env-major hand-over record; pgtt_physics +
+    pgtt_observe called on their own read the caller-visible rows.  Same bits either way - and a row the caller edits between the two calls is
+    what the observation then shows (the record must not shadow it)."""
+    n = 1000                                                 # ragged: the last physics wave is partly empty
+    a_env, _, _ = make(n=n, level="level13", interval_sums=True)
+    b_env, _, _ = make(n=n, level="level13", interval_sums=True)
+    a_env.reset(seed=5); b_env.reset(seed=5)
+    for k in range(30):
+        act = actions(k, n)
+        a_env.step(act)
+        b_env.physics(act); b_env.observe(act)
+    torch.cuda.synchronize()
+    sa, sb = snapshot(a_env), snapshot(b_env)
+    for key in sa:
+        assert torch.equal(sa[key].contiguous().view(torch.uint8), sb[key].contiguous().view(torch.uint8)), key
+    act = actions(30, n)
+    b_env.physics(act)
+    b_env.buffers["frame"][0].fill_(0.75)                    # PGTT_F_GYRO + 0 = observation row 0 (noise: +- noise_level * scale, 0.2 at most)
+    b_env.observe(act)
+    torch.cuda.synchronize()
+    live = b_env.buffers["done"] == 0                        # a finished episode shows its first observation instead
+    obs0 = b_env.buffers["obs_state"][:, 0][live]
+    assert int(live.sum()) > n // 2 and float((obs0 - 0.75).abs().max()) < 0.25
+    a_env.close(); b_env.close()
+
+
 def test_masked_reset_leaves_other_envs_untouched():
     env, _, _ = make()
     env.reset(seed=3)
