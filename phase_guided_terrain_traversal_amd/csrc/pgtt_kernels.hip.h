@@ -578,16 +578,42 @@ PG_INL void task_rewards(const float* sh_st, const float* sh_fr, const float* sh
 #pragma unroll
     for (int f = 0; f < 4; f++) phase[f] = fmod_once(phase[f] + phase_dt, (float)(2 * M_PI));
     timer -= 1;
-    if (timer <= 0) {
+    if constexpr (WAVE) {
+      // the waves that resample (1 - 2 % of a launch) are among the last to leave it: their four counter blocks (command y / z / w, timer)
+      // in ONE Philox pass, lanes 0..3, instead of four - same words as rng_uniform(.., stream, i) = word i of block 0 of the stream
+      if (done || timer <= 0) {
+        const int ln = (int)(threadIdx.x & 63);
+        unsigned c0 = id, c1 = ep, c2 = (unsigned)(ln == 0 ? PGTT_RS_CMD_Y : (ln == 1 ? PGTT_RS_CMD_Z : (ln == 2 ? PGTT_RS_CMD_W : PGTT_RS_TIMER))), c3 = 0u;
+        philox4x32_10((unsigned)a.seed, (unsigned)(a.seed >> 32), c0, c1, c2, c3);
+        auto uni = [&](unsigned w, int src) {
+          const float u = (float)((unsigned)__builtin_amdgcn_readlane((int)w, src) >> 8) * (1.0f / 16777216.0f);
+          return rng_fix == rng_fix ? rng_fix : u;
+        };
+        if (timer <= 0) {
+          const unsigned w[3] = {c0, c1, c2};
 #pragma unroll
-      for (int i = 0; i < 3; i++) {
-        float y = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_Y, i, rng_fix) * (cfg->cmd_u_max[i] - cfg->cmd_u_min[i]) + cfg->cmd_u_min[i];
-        float zb = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_Z, i, rng_fix) < cfg->cmd_b[i] ? 1.f : 0.f;
-        float wb = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_W, i, rng_fix) < 0.5f ? 1.f : 0.f;
-        cmd[i] = cmd[i] - wb * (cmd[i] - y * zb);
+          for (int i = 0; i < 3; i++) {
+            float y = uni(w[i], 0) * (cfg->cmd_u_max[i] - cfg->cmd_u_min[i]) + cfg->cmd_u_min[i];
+            float zb = uni(w[i], 1) < cfg->cmd_b[i] ? 1.f : 0.f;
+            float wb = uni(w[i], 2) < 0.5f ? 1.f : 0.f;
+            cmd[i] = cmd[i] - wb * (cmd[i] - y * zb);
+          }
+        }
+        const double t = -log1p(-(double)uni(c0, 3)) * 5.0;           // exp_timer
+        timer = (int)rint(t / (double)dt);
       }
+    } else {
+      if (timer <= 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          float y = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_Y, i, rng_fix) * (cfg->cmd_u_max[i] - cfg->cmd_u_min[i]) + cfg->cmd_u_min[i];
+          float zb = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_Z, i, rng_fix) < cfg->cmd_b[i] ? 1.f : 0.f;
+          float wb = rng_uniform(a.seed, id, ep, PGTT_RS_CMD_W, i, rng_fix) < 0.5f ? 1.f : 0.f;
+          cmd[i] = cmd[i] - wb * (cmd[i] - y * zb);
+        }
+      }
+      if (done || timer <= 0) timer = exp_timer(a.seed, id, ep, PGTT_RS_TIMER, dt, rng_fix);
     }
-    if (done || timer <= 0) timer = exp_timer(a.seed, id, ep, PGTT_RS_TIMER, dt, rng_fix);
     float sp = 0.f;
 #pragma unroll
     for (int f = 0; f < 4; f++) {
