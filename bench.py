@@ -216,7 +216,9 @@ def timed_window(env, n, steps, warmup, dev, rank, world, stub, sync):
     env.enable_timing(8)          # every 8th step: an event record costs a few us of GPU idle
     run(0, (100 if stub else PRIME_STEPS) + warmup)
     sums.zero_(); reducer.reduce(); env_steps_seen.zero_()               # counters back to zero (enqueued behind the warm-up steps)
-    env.enable_timing(8)                                   # timing counters back to zero: means are over the timed steps only (steps 4, 12, 20, ...)
+    # timing counters back to zero: means are over the timed steps only - steps 4, 12, 20, ... of a long window, the middle step of a short one
+    # (a timed step is ~10 us longer: three event records)
+    env.enable_timing(8 if steps >= 64 else max(2, steps))
     if world > 1:
         dist.barrier()
     sync()

@@ -60,6 +60,7 @@ struct pgtt_env {
   static constexpr int kRing = 64;
   hipEvent_t ev[kRing][4] = {};
   bool ev_used[kRing] = {};
+  bool ev_chain[kRing] = {};      // the observe launch of the slot started where its physics launch ended (pgtt_step): event 1 is its start, event 2 is not recorded
   int ev_slot = -1;               // slot of the most recent step
   double sum_phys = 0.0, sum_obs = 0.0; long n_timed = 0;
   bool ev_valid = false;
@@ -99,7 +100,7 @@ int harvest(pgtt_env* h, int r) {
   float p = 0.f, o = 0.f;
   HIP_TRY(hipEventSynchronize(h->ev[r][3]));
   HIP_TRY(hipEventElapsedTime(&p, h->ev[r][0], h->ev[r][1]));
-  HIP_TRY(hipEventElapsedTime(&o, h->ev[r][2], h->ev[r][3]));
+  HIP_TRY(hipEventElapsedTime(&o, h->ev[r][h->ev_chain[r] ? 1 : 2], h->ev[r][3]));
   h->sum_phys += p; h->sum_obs += o; h->n_timed++; h->ev_used[r] = false;
   return PGTT_OK;
 }
@@ -344,7 +345,7 @@ static int observe_impl(pgtt_handle h, const float* action, void* stream, bool s
   pgtt::KArgs a = make_args(h, nullptr, 0.f);
   if (same_step) a.handover_r = h->d_handover;
   const bool timed = h->timing_now && h->ev_slot >= 0;
-  if (timed) HIP_TRY(hipEventRecord(h->ev[h->ev_slot][2], st));
+  if (timed) { h->ev_chain[h->ev_slot] = same_step; if (!same_step) HIP_TRY(hipEventRecord(h->ev[h->ev_slot][2], st)); }      // an event record idles the device for ~3.5 us
   if (h->split_observe) {
     // scan + observation rows (one env per wave), then rewards / bookkeeping / wrapper (one env per lane)
     launch_observe<pgtt::OBS_STEP_OBS>(h, a, action, st);
@@ -410,7 +411,7 @@ int pgtt_last_kernel_ms(pgtt_handle h, float* physics_ms, float* observe_ms) {
   hipEvent_t* e = h->ev[h->ev_slot];
   HIP_TRY(hipEventSynchronize(e[3]));
   HIP_TRY(hipEventElapsedTime(physics_ms, e[0], e[1]));
-  HIP_TRY(hipEventElapsedTime(observe_ms, e[2], e[3]));
+  HIP_TRY(hipEventElapsedTime(observe_ms, e[h->ev_chain[h->ev_slot] ? 1 : 2], e[3]));
   return PGTT_OK;
 }
 
