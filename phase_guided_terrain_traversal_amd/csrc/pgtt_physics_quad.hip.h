@@ -1621,22 +1621,26 @@ struct QSolver {
     // Bracket update (mjx solver._update_bracket): a candidate y replaces the bracket end x when
     //   in_bracket(x, y) = (x.d0 < y.d0 < 0) or (x.d0 > y.d0 > 0),
     // tried in a fixed order, each test against the already updated end.  With u = d0 * sign(x.d0) (exact) this is a
-    // running "0 < u_y < u_x": a chain over ONE scalar; the winner's four fields are picked once at the end.
+    // running "0 < u_y < u_x": a chain over ONE scalar; the fields of the end follow every candidate that enters.
     // `frozen`: the env has left the search (its lanes only keep the wave company): threshold 0, nothing enters, the end stays as it is -
     // one select instead of an exec-mask region (save / branch / restore / branch, ~45 cycles of a one-wave SIMD) round the update
+    // Every test is ONE compare whose outcome feeds selects directly: a candidate that is not on the bracket's side (u_c <= 0 or NaN) is
+    // offered as +inf, so "0 < u_c < u" is the single `w < u`, and "something entered" is `u < u0` (an entering candidate lowers u strictly).
+    // The former `(u_c > 0) & (u_c < u)` met in SGPR pairs (v_cmp -> s_and_b64 -> v_cndmask): on a SIMD with one wave each such chain
+    // waits for the vector pipe to hand the mask to the scalar unit and back (tools/probes/issue_probe.hip: 33 cycles for four instructions).
     auto tighten = [](const LSPoint& x, const LSPoint& c1, const LSPoint& c2, const LSPoint& c3, bool frozen, bool& moved) {
       const float sg = x.d0 > 0.f ? 1.0f : -1.0f;
-      float u = frozen ? 0.f : x.d0 * sg;           // |x.d0| (0 if x.d0 == 0: nothing can enter the bracket)
-      const float u1 = c1.d0 * sg, u2 = c2.d0 * sg, u3 = c3.d0 * sg;
-      const bool k1 = (u1 > 0.f) & (u1 < u); u = k1 ? u1 : u;
-      const bool k2 = (u2 > 0.f) & (u2 < u); u = k2 ? u2 : u;
-      const bool k3 = (u3 > 0.f) & (u3 < u);
-      moved = k1 | k2 | k3;
-      LSPoint r;
-      r.alpha = k3 ? c3.alpha : (k2 ? c2.alpha : (k1 ? c1.alpha : x.alpha));
-      r.cost = 0.f;
-      r.d0 = k3 ? c3.d0 : (k2 ? c2.d0 : (k1 ? c1.d0 : x.d0));
-      r.d1 = k3 ? c3.d1 : (k2 ? c2.d1 : (k1 ? c1.d1 : x.d1));
+      const float u0 = frozen ? 0.f : x.d0 * sg;           // |x.d0| (0 if x.d0 == 0 or the env is frozen: nothing can enter the bracket)
+      float u = u0;
+      LSPoint r; r.alpha = x.alpha; r.cost = 0.f; r.d0 = x.d0; r.d1 = x.d1;
+      auto offer = [&](const LSPoint& c) {
+        const float uc = c.d0 * sg;
+        const float w = uc > 0.f ? uc : INFINITY;
+        const bool k = w < u;
+        u = k ? w : u; r.alpha = k ? c.alpha : r.alpha; r.d0 = k ? c.d0 : r.d0; r.d1 = k ? c.d1 : r.d1;
+      };
+      offer(c1); offer(c2); offer(c3);
+      moved = u < u0;
       return r;
     };
     PG_LTICK(s, 20);      // set-up: M s, J s, row hand-over, Gauss coefficients
