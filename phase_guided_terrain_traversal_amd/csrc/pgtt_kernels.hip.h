@@ -104,7 +104,17 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   bool valid = e < N;
   if (!valid) e = N - 1;                               // keep whole quads running (DPP), suppress the stores
   if (MODE != MODE_STEP && a.mask && !a.mask[e]) valid = false;
+  // Hex layout: the model constants (sizeof(PgttModel) = 2.5 KB, read ~100 times per substep through uniform or per-leg addresses) are staged
+  // in LDS once per launch: with one wave per SIMD every wait for a vector-memory round trip is exposed, and an LDS read returns in about
+  // half the time of an L1 hit (80 global loads of the step kernel became LDS reads: bit-identical, level4 168.0 -> 166.7 us, flat 118.1 ->
+  // 115.9 us at 4096 envs).  Not in the oct layout, where the change costs 52 B of scratch per lane and 0.5 - 0.8 %.
+  __shared__ unsigned sh_model[kSubs == 4 ? (sizeof(PgttModel) + 3) / 4 : 1];
   const PgttModel* __restrict__ m = a.model;
+  if (kSubs == 4) {
+    for (int i = threadIdx.x; i < (int)((sizeof(PgttModel) + 3) / 4); i += 64) sh_model[i] = reinterpret_cast<const unsigned*>(a.model)[i];
+    __syncthreads();
+    m = reinterpret_cast<const PgttModel*>(sh_model);
+  }
   const PgttConfig* __restrict__ cfg = a.cfg;
   float* __restrict__ S = a.buf.state;
   // Base-body rows are stored by ALL four lanes of the quad (same address, bit-identical value): the kernel has no
