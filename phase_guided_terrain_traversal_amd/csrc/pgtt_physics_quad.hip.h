@@ -1571,9 +1571,12 @@ struct QSolver {
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         const bool on = k < nslots;           // wave-uniform
-        qd_ja[2 * k] = f2{on ? slots.jar(k, 0) : 0.f, on ? slots.jar(k, 1) : 0.f}; qd_ja[2 * k + 1] = f2{on ? slots.jar(k, 2) : 0.f, on ? slots.jar(k, 3) : 0.f};
-        qd_jv[2 * k] = f2{on ? slots.jv(k, 0) : 0.f, on ? slots.jv(k, 1) : 0.f}; qd_jv[2 * k + 1] = f2{on ? slots.jv(k, 2) : 0.f, on ? slots.jv(k, 3) : 0.f};
-        qd_D[k] = on ? slots.at(k, 2) : 0.f;
+        // read first, select afterwards (see the hex layout below: otherwise every read sits in a branch of its own)
+        float a0 = slots.jar(k, 0), a1 = slots.jar(k, 1), a2 = slots.jar(k, 2), a3 = slots.jar(k, 3), v0 = slots.jv(k, 0), v1 = slots.jv(k, 1), v2 = slots.jv(k, 2), v3 = slots.jv(k, 3), dk = slots.at(k, 2);
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(dk));
+        qd_ja[2 * k] = f2{on ? a0 : 0.f, on ? a1 : 0.f}; qd_ja[2 * k + 1] = f2{on ? a2 : 0.f, on ? a3 : 0.f};
+        qd_jv[2 * k] = f2{on ? v0 : 0.f, on ? v1 : 0.f}; qd_jv[2 * k + 1] = f2{on ? v2 : 0.f, on ? v3 : 0.f};
+        qd_D[k] = on ? dk : 0.f;
       }
     }
     if (kSubs == 2) {
@@ -1588,9 +1591,11 @@ struct QSolver {
 #pragma unroll
         for (int k = 0; k < kMaxB; k++) {
           const bool on = k < units();          // wave-uniform
-          qd_ja[k] = f2{on ? slots.jar(k, r0) : 0.f, on ? slots.jar(k, r0 + 1) : 0.f};
-          qd_jv[k] = f2{on ? slots.jv(k, r0) : 0.f, on ? slots.jv(k, r0 + 1) : 0.f};
-          oc_D[k] = on ? slots.at(k, 2) : 0.f;
+          float a0 = slots.jar(k, r0), a1 = slots.jar(k, r0 + 1), v0 = slots.jv(k, r0), v1 = slots.jv(k, r0 + 1), dk = slots.at(k, 2);      // read first, select afterwards
+          asm volatile("" : "+v"(a0), "+v"(a1), "+v"(v0), "+v"(v1), "+v"(dk));
+          qd_ja[k] = f2{on ? a0 : 0.f, on ? a1 : 0.f};
+          qd_jv[k] = f2{on ? v0 : 0.f, on ? v1 : 0.f};
+          oc_D[k] = on ? dk : 0.f;
         }
       }
     }
@@ -1607,9 +1612,13 @@ struct QSolver {
       for (int p = 0; p < 2; p++) {
         const int k = 2 * p, k1 = 2 * p + 1;
         const bool on0 = k < nslots, on1 = k1 < nslots;           // wave-uniform
-        ls_ja[p] = f2{on0 ? slots.jar(k, r) : 0.f, on1 ? slots.jar(k1, r) : 0.f};
-        ls_jv[p] = f2{on0 ? slots.jv(k, r) : 0.f, on1 ? slots.jv(k1, r) : 0.f};
-        ls_D[p] = f2{on0 ? slots.at(k, 2) : 0.f, on1 ? slots.at(k1, 2) : 0.f};
+        // read first, select afterwards: with `on ? slots.x : 0.f` the compiler wraps every one of the twelve LDS reads in a branch of its own
+        // (scalar mask test + s_cbranch, some with the mask negated through the vector unit): ~200 cycles of a one-wave SIMD per search
+        float a0 = slots.jar(k, r), a1 = slots.jar(k1, r), v0 = slots.jv(k, r), v1 = slots.jv(k1, r), d0 = slots.at(k, 2), d1 = slots.at(k1, 2);
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(v0), "+v"(v1), "+v"(d0), "+v"(d1));
+        ls_ja[p] = f2{on0 ? a0 : 0.f, on1 ? a1 : 0.f};
+        ls_jv[p] = f2{on0 ? v0 : 0.f, on1 ? v1 : 0.f};
+        ls_D[p] = f2{on0 ? d0 : 0.f, on1 ? d1 : 0.f};
       }
     }
     float ab = 0.f, bb_ = 0.f, eb = 0.f, al = 0.f, bl = 0.f, el = 0.f;
@@ -1762,7 +1771,9 @@ struct QSolver {
 #pragma unroll
       for (int k = 0; k < 3; k++) gnl += gl[k] * gl[k];
       float gn = gnb + quad_sum(gnl);
-      bool done = niter >= m->iterations || (div_normal(prev_cost - cost, scale) < m->tolerance) || (div_normal(sqrtf(gn), scale) < m->tolerance);
+      // `|`, not `||`: the three tests are per-env values, and short-circuit evaluation of a per-lane condition is an exec-mask region each
+      const bool d_it = niter >= m->iterations, d_imp = div_normal(prev_cost - cost, scale) < m->tolerance, d_grad = div_normal(sqrtf(gn), scale) < m->tolerance;
+      bool done = d_it | d_imp | d_grad;
       if (__ballot(!done) == 0ull) break;
       PG_TICK(s, 9);
       linesearch(done);
