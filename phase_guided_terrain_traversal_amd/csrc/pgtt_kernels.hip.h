@@ -108,12 +108,17 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   // in LDS once per launch: with one wave per SIMD every wait for a vector-memory round trip is exposed, and an LDS read returns in about
   // half the time of an L1 hit (80 global loads of the step kernel became LDS reads: bit-identical, level4 168.0 -> 166.7 us, flat 118.1 ->
   // 115.9 us at 4096 envs).  Not in the oct layout, where the change costs 52 B of scratch per lane and 0.5 - 0.8 %.
+  // Order of the prologue: the variant index first (two dependent round trips hang on it: index -> box records), then every other load of
+  // the launch - model image, per-env model, state rows, action - and ONE barrier behind all the staging stores; the prologue reads the
+  // model through its global pointer (gm), everything after the barrier through `m`.
   __shared__ unsigned sh_model[kSubs == 4 ? (sizeof(PgttModel) + 3) / 4 : 1];
-  const PgttModel* __restrict__ m = a.model;
+  const PgttModel* __restrict__ gm = a.model;
+  const int variant = (HAS_TERRAIN && a.buf.variant) ? a.buf.variant[e] : 0;
+  constexpr int kModelWords = (int)((sizeof(PgttModel) + 3) / 4), kModelTrips = (kModelWords + 63) / 64;
+  unsigned mw[kSubs == 4 ? kModelTrips : 1];
   if (kSubs == 4) {
-    for (int i = threadIdx.x; i < (int)((sizeof(PgttModel) + 3) / 4); i += 64) sh_model[i] = reinterpret_cast<const unsigned*>(a.model)[i];
-    __syncthreads();
-    m = reinterpret_cast<const PgttModel*>(sh_model);
+#pragma unroll
+    for (int t = 0; t < kModelTrips; t++) { const int i = t * 64 + (int)threadIdx.x; mw[t] = reinterpret_cast<const unsigned*>(a.model)[i < kModelWords ? i : 0]; }
   }
   const PgttConfig* __restrict__ cfg = a.cfg;
   float* __restrict__ S = a.buf.state;
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   const bool lead = valid;
 
   QEnvModel em;
-  qload_env_model<HAS_DR>(m, a.buf.params, N, e, l, em);
+  qload_env_model<HAS_DR>(gm, a.buf.params, N, e, l, em);
   QSim s;
 #ifdef PGTT_TIME
   s.tlast = t0_cyc;
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
     s.ql[k] = S[(PGTT_S_QPOS + 7 + j) * (long)N + e];
     s.vl[k] = S[(PGTT_S_QVEL + 6 + j) * (long)N + e];
     s.wl[k] = S[(PGTT_S_QWARM + 6 + j) * (long)N + e];
-    if (MODE == MODE_STEP) s.ctrl[k] = m->key_qpos[7 + ac] + action[(long)e * 12 + ac] * cfg->action_scale;
+    if (MODE == MODE_STEP) s.ctrl[k] = gm->key_qpos[7 + ac] + action[(long)e * 12 + ac] * cfg->action_scale;
     else s.ctrl[k] = S[(PGTT_S_QPOS + 7 + ac) * (long)N + e];          // mjx_env.init(ctrl = qpos[7:])
   }
   const TerrainBox* boxes = nullptr;
@@ -151,9 +156,8 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   const int quad = lane_env();                         // env within the wave
   const BoxSlots slots{sh_con, lane_col()};
   if (HAS_TERRAIN) {
-    int v = a.buf.variant ? a.buf.variant[e] : 0;
-    boxes = a.terrain + (long)v * a.B;
-    grid_v = a.grid + (long)v * (kGridG * kGridG);
+    boxes = a.terrain + (long)variant * a.B;
+    grid_v = a.grid + (long)variant * (kGridG * kGridG);
     nbox = a.B;
     for (int b = lane_in_env(); b < nbox; b += 4 * kSubs) {
       const TerrainBox* tb = boxes + b;
@@ -161,8 +165,14 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
       sh_box2[b * kEnvsPerWave + quad] = make_float2(tb->hy, tb->hz);
     }
     slots.clear_all();
-    __syncthreads();
   }
+  const PgttModel* __restrict__ m = gm;
+  if (kSubs == 4) {
+#pragma unroll
+    for (int t = 0; t < kModelTrips; t++) { const int i = t * 64 + (int)threadIdx.x; if (i < kModelWords) sh_model[i] = mw[t]; }
+    m = reinterpret_cast<const PgttModel*>(sh_model);
+  }
+  if (HAS_TERRAIN || kSubs == 4) __syncthreads();
   s.niter = 0; s.niter_max = 0; s.pen_overflow = false;
   QPhysics ph(m, em, s, l);
   QSolver sol(m, s, slots);
