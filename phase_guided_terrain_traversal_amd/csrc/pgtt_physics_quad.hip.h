@@ -1015,14 +1015,16 @@ struct QPhysics {
     // is the own pair (d, rank r, scan order ord) among the nslot best of the env's table?
     auto selected = [&](float d, int r, bool okm, int ord) {
       int beat = 0;
+      // candidate columns outermost: ONE wave-uniform test per column in use instead of one per table entry (the count is an integer sum)
 #pragma unroll
-      for (int j = 0; j < 4; j++)
+      for (int i2 = 0; i2 < kMaxPenQ; i2++) {
+        if (i2 >= ncol) continue;
 #pragma unroll
-        for (int i2 = 0; i2 < kMaxPenQ; i2++) {
-          if (i2 >= ncol) continue;
+        for (int j = 0; j < 4; j++) {
           const bool first = (cdist[j][i2] < d) | ((cdist[j][i2] == d) & (((unsigned)crank[j][i2] < (unsigned)r) | ((crank[j][i2] == r) & (j * kMaxPenQ + i2 < ord))));
           beat += (ok[j][i2] & first) ? 1 : 0;
         }
+      }
       return okm & (beat < nslot);
     };
     int nb = 0;
