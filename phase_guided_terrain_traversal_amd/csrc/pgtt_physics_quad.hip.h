@@ -1007,11 +1007,10 @@ struct QPhysics {
     // scan order leg-major): MJX's sequential top-k picks exactly the pairs that fewer than max_contact_points others
     // beat, so every lane only ranks its OWN pairs against the table — no selection rounds.
     const int nslot = (maxc > -1 && maxc < 4) ? maxc : 4;
-    bool ok[4][kMaxPenQ];
-#pragma unroll
-    for (int i = 0; i < kMaxPenQ; i++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) ok[j][i] = (cdist[j][i] < 0.f) & !((broad & need_exact) & (crank[j][i] >= maxp));
+    // "still in the table" (penetrating and not removed by the max_geom_pairs cut) is formed where an entry is looked at, i.e. for the columns
+    // in use only - as a table of sixteen masks it was computed in full and kept alive in SGPR pairs (spilled through v_writelane / v_readlane)
+    const bool cut = broad & need_exact;
+    auto ok = [&](int j, int i) { return (cdist[j][i] < 0.f) & !(cut & (crank[j][i] >= maxp)); };
     // is the own pair (d, rank r, scan order ord) among the nslot best of the env's table?
     auto selected = [&](float d, int r, bool okm, int ord) {
       int beat = 0;
@@ -1022,7 +1021,7 @@ struct QPhysics {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const bool first = (cdist[j][i2] < d) | ((cdist[j][i2] == d) & (((unsigned)crank[j][i2] < (unsigned)r) | ((crank[j][i2] == r) & (j * kMaxPenQ + i2 < ord))));
-          beat += (ok[j][i2] & first) ? 1 : 0;
+          beat += (ok(j, i2) & first) ? 1 : 0;
         }
       }
       return okm & (beat < nslot);
@@ -1036,7 +1035,7 @@ struct QPhysics {
         // own pair (l, i): values through selects on the leg index
         const float d = sel4(l, cdist[0][i], cdist[1][i], cdist[2][i], cdist[3][i]);
         const int r = l == 0 ? crank[0][i] : (l == 1 ? crank[1][i] : (l == 2 ? crank[2][i] : crank[3][i]));
-        const bool okm = l == 0 ? ok[0][i] : (l == 1 ? ok[1][i] : (l == 2 ? ok[2][i] : ok[3][i]));
+        const bool okm = (d < 0.f) & !(cut & (r >= maxp));
         mine[i] = selected(d, r, okm, l * kMaxPenQ + i);
       }
       // own selected pairs: park (dist, box, point, normal) in the slot records
