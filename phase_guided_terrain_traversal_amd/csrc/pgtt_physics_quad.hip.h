@@ -69,6 +69,7 @@ PG_INL float quad_sum(float x) {
   return x;
 }
 PG_INL int quad_sum_i(int x) { x += dpp_i<kLegStep1>(x); x += dpp_i<kLegStep2>(x); return x; }
+PG_INL float quad_max(float x) { x = fmaxf(x, dpp_f<kLegStep1>(x)); x = fmaxf(x, dpp_f<kLegStep2>(x)); return x; }      // max over the legs (exact, order-free)
 PG_INL V3 quad_sum(V3 a) { return v3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)); }
 // sum over the sub-lanes of a leg (four in the hex layout, two neighbours in the oct layout; identity in the quad layout)
 PG_INL float sub_sum(float x) {
@@ -892,7 +893,7 @@ struct QPhysics {
       float kmax = -3.0e38f;
 #pragma unroll
       for (int i = 0; i < kMaxPenQ; i++) kmax = fmaxf(kmax, pen[i].dist < 0.f ? pen[i].key : -3.0e38f);
-      kmax = fmaxf(fmaxf(quad_bcast<0>(kmax), quad_bcast<1>(kmax)), fmaxf(quad_bcast<2>(kmax), quad_bcast<3>(kmax)));
+      kmax = quad_max(kmax);       // two butterfly steps instead of four leg broadcasts (in the hex / oct layouts: 3 rotations + 3 selects each)
       const float thr = (kmax + keyC) * 1.000002f + 1e-7f, thr2 = kmax > -1.0e38f ? thr * thr : -1.f;
       int cnt = 0;
       static_assert(PGTT_MAX_BOX <= 128, "hex layout: the <= 32 boxes of a sub-lane are one mask word");
@@ -984,13 +985,7 @@ struct QPhysics {
       // (key, pair index) pairs, and the pair index grows with the scan order of the table: when some env of the wave has
       // more penetrating pairs than slots, the rank column is filled with the keys themselves (order-preserving float ->
       // uint map; the selection compares ranks as unsigned numbers) - no tables beyond the ones that are live anyway.
-      int npn = 0;
-#pragma unroll
-      for (int i = 0; i < kMaxPenQ; i++) {
-        if (i >= ncol) continue;
-#pragma unroll
-        for (int j = 0; j < 4; j++) npn += cdist[j][i] < 0.f ? 1 : 0;
-      }
+      const int npn = quad_sum_i(npen);       // penetrating pairs of the env = the table entries with a negative depth
       const int nslot0 = (maxc > -1 && maxc < 4) ? maxc : 4;
       if (broad && __ballot(npn > nslot0) != 0ull) {
 #pragma unroll
