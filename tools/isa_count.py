@@ -20,4 +20,4 @@ def count(path):
         c[k] += 1
     return c
 for p in sys.argv[1:]:
-    c = count(p); print(p.split('/')[-2], sum(c.values()), dict(sorted(c.items())))
+    c = count(p); print(p, sum(c.values()), dict(sorted(c.items())))
