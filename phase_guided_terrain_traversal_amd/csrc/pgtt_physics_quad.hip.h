@@ -413,6 +413,9 @@ struct QPhysics {
   QSim& s;
   const int l;      // own leg
   PG_INL QPhysics(const PgttModel* m_, const QEnvModel& em_, QSim& s_, int l_) : m(m_), em(em_), s(s_), l(l_) {}
+  // pass 2a of collide(), remembered across the substeps of a launch: where the own foot stood and the (inflated) radius for which the env's
+  // pair count was last found <= max_geom_pairs; c2_thr < 0: nothing remembered
+  V3 c2_foot = v3(0, 0, 0); float c2_thr = -1.f;
 
   PG_INL void body_inertia(int mb, V3 xp, Q4 xq, V3 ipos, float mass, V3& xipos, float* Iw) const {
     xipos = xp + qrot(ipos, xq);
@@ -895,17 +898,38 @@ struct QPhysics {
       for (int i = 0; i < kMaxPenQ; i++) kmax = fmaxf(kmax, pen[i].dist < 0.f ? pen[i].key : -3.0e38f);
       kmax = quad_max(kmax);       // two butterfly steps instead of four leg broadcasts (in the hex / oct layouts: 3 rotations + 3 selects each)
       const float thr = (kmax + keyC) * 1.000002f + 1e-7f, thr2 = kmax > -1.0e38f ? thr * thr : -1.f;
+      // The count is a PROOF (every candidate survives the max_geom_pairs cut), and a proof can be carried over: if an earlier substep of this
+      // launch counted, with every foot at f_ref and a radius R, no more than max_geom_pairs pairs, then by the triangle inequality every box
+      // within thr of a foot that has moved by d <= R - thr is among the boxes counted then - the count of this substep cannot exceed that one.
+      // On the shipped terrains the count is ~3 of the 25 allowed, so R is generous (thr + 0.1 m) and the 100-box pass runs once per launch.
+      {
+        const bool holds = (thr2 < 0.f) | ((c2_thr >= 0.f) & ((norm(s.footc - c2_foot) + thr) * 1.0001f + 1e-5f <= c2_thr));      // own foot
+        if (__ballot(!holds) == 0ull) goto counted;           // every foot of every env of the wave: need_exact stays false
+      }
+      {
       int cnt = 0;
+      int cnt_r = 0;
+      const float thr_r = thr + 0.1f, thr_r2 = thr_r * thr_r;
       static_assert(PGTT_MAX_BOX <= 128, "hex layout: the <= 32 boxes of a sub-lane are one mask word");
 #pragma unroll 4
       for (int t = 0, b = lane_sub(); b < nbox; t++, b += kSubs) {     // hex / oct: boxes go round the sub-lanes
         const float4 A = sh_box[b * kEnvsPerWave + quad];
         V3 dv = v3(A.x, A.y, A.z) - s.footc;
-        const bool in = dot(dv, dv) <= thr2;
+        const float d2 = dot(dv, dv);
+        const bool in = d2 <= thr2;
         cnt += in ? 1 : 0;
+        cnt_r += d2 <= thr_r2 ? 1 : 0;
         if (kSubs == 4) nearmask |= (in ? 1u : 0u) << t;     // own boxes that can sort before a candidate (pass 2b)
       }
       need_exact = quad_sum_i(sub_sum_i(cnt)) > maxp;
+      // remember the wider count when it is a proof as well (an env without a candidate has thr2 < 0 and needs none)
+      c2_foot = s.footc;
+      c2_thr = (thr2 >= 0.f && quad_sum_i(sub_sum_i(cnt_r)) <= maxp) ? thr_r : -1.f;
+      }
+      counted:;
+#ifdef PGTT_TIME
+      { const float c = (float)quad_sum_i(sub_sum_i(cnt)); s.cyc[25] += c; s.cyc[26] = fmaxf(s.cyc[26], c); }
+#endif
     }
     if (broad && __ballot(need_exact) != 0ull) {
       // pass 2b (rare, but the wave that takes it is the one the launch waits for): exact broad-phase rank = number of
