@@ -904,6 +904,9 @@ struct QPhysics {
       // On the shipped terrains the count is ~3 of the 25 allowed, so R is generous (thr + 0.1 m) and the 100-box pass runs once per launch.
       {
         const bool holds = (thr2 < 0.f) | ((c2_thr >= 0.f) & ((norm(s.footc - c2_foot) + thr) * 1.0001f + 1e-5f <= c2_thr));      // own foot
+#ifdef PGTT_TIME
+        s.cyc[26] += __ballot(!holds) == 0ull ? 1.f : 0.f;       // substeps in which the wave carries the proof over
+#endif
         if (__ballot(!holds) == 0ull) goto counted;           // every foot of every env of the wave: need_exact stays false
       }
       {
@@ -922,14 +925,14 @@ struct QPhysics {
         if (kSubs == 4) nearmask |= (in ? 1u : 0u) << t;     // own boxes that can sort before a candidate (pass 2b)
       }
       need_exact = quad_sum_i(sub_sum_i(cnt)) > maxp;
+#ifdef PGTT_TIME
+      s.cyc[25] += (float)quad_sum_i(sub_sum_i(cnt));      // pairs counted by the passes of this launch (own env)
+#endif
       // remember the wider count when it is a proof as well (an env without a candidate has thr2 < 0 and needs none)
       c2_foot = s.footc;
       c2_thr = (thr2 >= 0.f && quad_sum_i(sub_sum_i(cnt_r)) <= maxp) ? thr_r : -1.f;
       }
       counted:;
-#ifdef PGTT_TIME
-      { const float c = (float)quad_sum_i(sub_sum_i(cnt)); s.cyc[25] += c; s.cyc[26] = fmaxf(s.cyc[26], c); }
-#endif
     }
     if (broad && __ballot(need_exact) != 0ull) {
       // pass 2b (rare, but the wave that takes it is the one the launch waits for): exact broad-phase rank = number of

@@ -30,4 +30,4 @@ for i in list(range(10)) + list(range(11, 17)):
     print(f"  {names[i]:22s} {acc[i] / 40:12.0f} ticks/step  {100 * acc[i] / tot:5.1f} %")
 for i, nm in zip(range(24, 29), ("  ls: set-up (M s, J s, rows, Gauss terms)", "  ls: two initial points", "  ls: bracketing rounds", "  ls: final costs", "  ls: update")):
     print(f"  {nm:42s} {acc[i] / 40:12.0f} ticks/step  {100 * acc[i] / tot:5.1f} %")
-print(f"  broad-phase count of pass 2a, env {os.environ.get('PGTT_TIME_ENV', '0')} (pairs at least as close as the farthest candidate; exact ranks are needed above max_geom_pairs = 25): mean per substep {acc[29] / 160:.1f}, mean over the steps of the largest of the four {acc[30] / 40:.1f}")
+print(f"  broad-phase count of pass 2a, env 0 (pairs at least as close as the farthest candidate; exact ranks are needed above max_geom_pairs = 25): sum over the passes of a control step {acc[29] / 40:.1f}; substeps per control step in which the wave carries the proof over instead of counting: {acc[30] / 40:.2f} of 4")
