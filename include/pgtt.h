@@ -235,8 +235,9 @@ typedef struct PgttBuffers {
   int32_t* dbg_contact;  /* [N][PGTT_NCON][2] (foot 0..3 FL,FR,RL,RR ; geom: -1 plane, box idx, -2 none) or NULL */
   float*   dbg_dist;     /* [N][PGTT_NCON] or NULL */
   int32_t* dbg_niter;    /* [N] low 16 bits: max Newton iterations over the substeps of the last physics call (== iterations => truncated);
-                          * bit PGTT_DBG_PEN_OVERFLOW: some foot met more than 4 simultaneously penetrating boxes in a substep (the 4 deepest
-                          * pairs of the foot were kept; MJX's max_geom_pairs cut is not re-examined for the dropped ones).  Or NULL */
+                          * bit PGTT_DBG_PEN_OVERFLOW (informational): some foot met more than 4 simultaneously penetrating boxes in a substep
+                          * and the wave took the exact many-box pass of the collision stage (same contact set as MJX's max_geom_pairs /
+                          * max_contact_points selection, only slower).  Or NULL */
   /* [PGTT_NMETRIC + 2][N] or NULL: per-env running sums of the step outputs (22 metrics, reward, done) since the caller last
    * cleared the block.  The reference's trainer averages the Episode-wrapper metrics per log interval (training/train.py:198-229);
    * with the sums kept by the step itself a logging interval costs ONE reduction over the envs instead of one per step. */

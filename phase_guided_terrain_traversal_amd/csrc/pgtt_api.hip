@@ -152,7 +152,7 @@ int check_ready(pgtt_env* h) {
 extern "C" {
 
 const char* pgtt_last_error(void) { return g_err.c_str(); }
-const char* pgtt_version(void) { return "pgtt-mi355x 0.1 (gfx950)"; }
+const char* pgtt_version(void) { return "pgtt-mi355x 0.4 (gfx950)"; }
 int pgtt_obs_dims(const PgttConfig* cfg, int* state_dim, int* priv_dim) {
   if (!cfg || !state_dim || !priv_dim) return fail(PGTT_E_ARG, "pgtt_obs_dims: null argument");
   if (cfg->method != PGTT_METHOD_PGTT && cfg->method != PGTT_METHOD_BASELINE) return fail(PGTT_E_ARG, "pgtt_obs_dims: unknown method");
@@ -191,12 +191,17 @@ int pgtt_create(const PgttConfig* cfg, const PgttModel* model, int device, int n
   // lane-parallel) is faster than the split form at every batch size measured (16384 envs: 0.088 against 0.135 ms)
   h->layout = cfg->lane_layout;
   h->split_observe = cfg->observe_form == PGTT_OBSERVE_SPLIT;
-  HIP_TRY(hipMalloc(&h->d_cfg, sizeof(PgttConfig)));
-  HIP_TRY(hipMalloc(&h->d_model, sizeof(PgttModel)));
-  HIP_TRY(hipMalloc(&h->d_handover, (size_t)num_envs * pgtt::kHandover * sizeof(float)));
-  HIP_TRY(hipMemcpy(h->d_cfg, cfg, sizeof(PgttConfig), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->d_model, model, sizeof(PgttModel), hipMemcpyHostToDevice));
-  for (int r = 0; r < pgtt_env::kRing; r++) for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&h->ev[r][i]));
+  // a failure half way frees what the call allocated so far (pgtt_destroy walks the same fields)
+  auto built = [&]() -> int {
+    HIP_TRY(hipMalloc(&h->d_cfg, sizeof(PgttConfig)));
+    HIP_TRY(hipMalloc(&h->d_model, sizeof(PgttModel)));
+    HIP_TRY(hipMalloc(&h->d_handover, (size_t)num_envs * pgtt::kHandover * sizeof(float)));
+    HIP_TRY(hipMemcpy(h->d_cfg, cfg, sizeof(PgttConfig), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_model, model, sizeof(PgttModel), hipMemcpyHostToDevice));
+    for (int r = 0; r < pgtt_env::kRing; r++) for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&h->ev[r][i]));
+    return PGTT_OK;
+  };
+  if (int rc = built()) { pgtt_destroy(h); return rc; }
   *out = h;
   return PGTT_OK;
 }

@@ -742,8 +742,9 @@ struct QPhysics {
     // AABB touches it (border cells reach to infinity).  The foot's cell gives a small candidate set, and only those boxes go
     // through the exact AABB test against the LDS-resident centres / extents - the outcome mask is identical to testing all
     // boxes (the cell sets are supersets), at a few LDS rows per foot instead of one hundred.
-    unsigned cm[4] = {0u, 0u, 0u, 0u};
-    {
+    unsigned cm[4];
+    auto candidates = [&]() {
+      cm[0] = 0u; cm[1] = 0u; cm[2] = 0u; cm[3] = 0u;
       const float pad = rad + 1e-5f;
       const float fx = s.footc.x, fy = s.footc.y, fz = s.footc.z;
       const int ix = min(max((int)floorf((fx + grid_E) * grid_inv), 0), kGridG - 1), iy = min(max((int)floorf((fy + grid_E) * grid_inv), 0), kGridG - 1);
@@ -770,7 +771,8 @@ struct QPhysics {
         cm[0] |= w == 0 ? hit : 0u; cm[1] |= w == 1 ? hit : 0u; cm[2] |= w == 2 ? hit : 0u; cm[3] |= w == 3 ? hit : 0u;
       }
       if (kSubs > 1) { cm[0] = sub_or(cm[0]); cm[1] = sub_or(cm[1]); cm[2] = sub_or(cm[2]); cm[3] = sub_or(cm[3]); }
-    }
+    };
+    candidates();
     PG_TICK(s, 12);
     // pass 1b: narrow phase on the candidates in box order (every lane pops its own lowest set bit); penetrating pairs kept
     QPen pen[kMaxPenQ]; int npen = 0;
@@ -800,26 +802,7 @@ struct QPhysics {
       slots.at(at, 7) = pw.x; slots.at(at, 8) = pw.y; slots.at(at, 9) = pw.z;
       slots.at(at, 10) = nw.x; slots.at(at, 11) = nw.y; slots.at(at, 12) = nw.z;
     };
-    // MORE than kMaxPenQ boxes penetrated by one foot at once (never on the shipped / generated terrains - at most three boxes meet at a
-    // seam - but reachable through pgtt_set_terrain): MJX ranks all pairs by centre distance, cuts at max_geom_pairs and keeps the
-    // max_contact_points DEEPEST of the env, so a foot can never need more than its kMaxPenQ deepest pairs - unless the rank cut removes
-    // one of them.  The table therefore keeps the kMaxPenQ deepest pairs of the foot (a newcomer replaces the shallowest entry when it is
-    // deeper; equal depth: the entry stays) and the call raises PGTT_DBG_PEN_OVERFLOW in dbg_niter, because with replaced entries the
-    // table is no longer in scan order (the tie rule of the selection below) and the rank cut is not re-examined for the dropped pairs.
-    // `mine`: this lane computed the pair and parks its contact point / normal.  Only reached through the wave-uniform test below.
-    auto keep_deepest = [&](const QPen& g, bool mine, V3 pw, V3 nw) {
-      const bool pen_new = g.dist < 0.f, room = npen < kMaxPenQ;
-      int imax = 0; float dmax = pen[0].dist;
-#pragma unroll
-      for (int i = 1; i < kMaxPenQ; i++) { const bool later = pen[i].dist >= dmax; dmax = later ? pen[i].dist : dmax; imax = later ? i : imax; }
-      const bool put = pen_new & (room | (g.dist < dmax));
-      const int at = room ? npen : imax;
-#pragma unroll
-      for (int i = 0; i < kMaxPenQ; i++) { const bool hit = put & (i == at); pen[i].dist = hit ? g.dist : pen[i].dist; pen[i].key = hit ? g.key : pen[i].key; pen[i].idx = hit ? g.idx : pen[i].idx; }
-      npen += (pen_new & room) ? 1 : 0;
-      if (put & mine) park(at, pw, nw);
-      s.pen_overflow |= pen_new & !room;
-    };
+    bool redo = false;      // wave-uniform: some foot of the wave penetrates more than kMaxPenQ boxes -> collide_many() below
     for (;;) {
       if (__ballot((cm[0] | cm[1] | cm[2] | cm[3]) != 0u) == 0ull) break;
       int b;
@@ -843,16 +826,13 @@ struct QPhysics {
       sphere_box(s.footc, rad, tb, nd, pw, nw);
       QPen pp; pp.dist = have ? nd : 1.f; pp.key = norm(v3(tb.px, tb.py, tb.pz) - s.footc) - keyC; pp.idx = l * nbox + (have ? b : 0);
       if (kSubs == 1) {
-        if (__builtin_expect(__ballot((pp.dist < 0.f) & (npen >= kMaxPenQ)) != 0ull, 0)) { keep_deepest(pp, true, pw, nw); continue; }
+        if (__builtin_expect(__ballot((pp.dist < 0.f) & (npen >= kMaxPenQ)) != 0ull, 0)) { redo = true; break; }
         if ((pp.dist < 0.f) & (npen < kMaxPenQ)) park(npen, pw, nw);
         keep(pp);
       } else if (kSubs == 2) {
         QPen g0{sub_bcast<0>(pp.dist), sub_bcast<0>(pp.key), sub_bcast<0>(pp.idx)}, g1{sub_bcast<1>(pp.dist), sub_bcast<1>(pp.key), sub_bcast<1>(pp.idx)};
         const int before = ((threadIdx.x & 1) && g0.dist < 0.f) ? 1 : 0;
-        if (__builtin_expect(__ballot(npen + (g0.dist < 0.f ? 1 : 0) + (g1.dist < 0.f ? 1 : 0) > kMaxPenQ) != 0ull, 0)) {
-          keep_deepest(g0, (threadIdx.x & 1) == 0, pw, nw); keep_deepest(g1, (threadIdx.x & 1) == 1, pw, nw);
-          continue;
-        }
+        if (__builtin_expect(__ballot(npen + (g0.dist < 0.f ? 1 : 0) + (g1.dist < 0.f ? 1 : 0) > kMaxPenQ) != 0ull, 0)) { redo = true; break; }
         if ((pp.dist < 0.f) & (npen + before < kMaxPenQ)) park(npen + before, pw, nw);
         keep(g0); keep(g1);
       } else {
@@ -861,15 +841,110 @@ struct QPhysics {
         QPen g0{sub_bcast<0>(pp.dist), sub_bcast<0>(pp.key), sub_bcast<0>(pp.idx)}, g1{sub_bcast<1>(pp.dist), sub_bcast<1>(pp.key), sub_bcast<1>(pp.idx)};
         QPen g2{sub_bcast<2>(pp.dist), sub_bcast<2>(pp.key), sub_bcast<2>(pp.idx)}, g3{sub_bcast<3>(pp.dist), sub_bcast<3>(pp.key), sub_bcast<3>(pp.idx)};
         const int f0 = g0.dist < 0.f ? 1 : 0, f1 = g1.dist < 0.f ? 1 : 0, f2 = g2.dist < 0.f ? 1 : 0;
-        if (__builtin_expect(__ballot(npen + f0 + f1 + f2 + (g3.dist < 0.f ? 1 : 0) > kMaxPenQ) != 0ull, 0)) {
-          keep_deepest(g0, r == 0, pw, nw); keep_deepest(g1, r == 1, pw, nw); keep_deepest(g2, r == 2, pw, nw); keep_deepest(g3, r == 3, pw, nw);
-          continue;
-        }
+        if (__builtin_expect(__ballot(npen + f0 + f1 + f2 + (g3.dist < 0.f ? 1 : 0) > kMaxPenQ) != 0ull, 0)) { redo = true; break; }
         const bool h0 = (r & 1) != 0, h1 = (r & 2) != 0;
         const int before = h1 ? (h0 ? f0 + f1 + f2 : f0 + f1) : (h0 ? f0 : 0);        // penetrating pairs of the lower sub-lanes
         if ((pp.dist < 0.f) & (npen + before < kMaxPenQ)) park(npen + before, pw, nw);
         keep(g0); keep(g1); keep(g2); keep(g3);
       }
+    }
+    if (__builtin_expect(redo, 0)) {
+      // ---- MORE than kMaxPenQ boxes penetrated by one foot at once (never on the shipped / generated terrains - at most three boxes meet at
+      // a seam - but reachable through pgtt_set_terrain).  MJX ranks all 4 * nbox pairs by centre distance, cuts at max_geom_pairs and keeps
+      // the max_contact_points DEEPEST survivors of the env, equal depths in broad-phase order (go2_mjx_feetonly.xml:14-15 -> base.py:153-171).
+      // Of one foot only its kMaxPenQ best SURVIVING pairs can be among them, so the pass is run again for the whole wave with a table that
+      // keeps exactly those: a pair enters only if it survives the rank cut (exact rank over the env's pairs, when the cut can bite at all),
+      // and a full table drops its last entry in MJX's order - depth, then (key, pair index), or the pair index alone where the broad phase
+      // does not sort.  Entries stay in scan order (the tie rule of the selection below), which then runs unchanged on the right table.
+      // Every sub-lane of a leg does the whole of its leg's work here (replicated, bit-identical); the call raises PGTT_DBG_PEN_OVERFLOW.
+      candidates();
+      npen = 0;
+#pragma unroll
+      for (int i = 0; i < kMaxPenQ; i++) { pen[i].dist = 1.f; pen[i].key = 3.0e38f; pen[i].idx = 0x7fffffff; }
+      bool cutting = false;      // per env: the max_geom_pairs cut may remove a candidate
+      if (broad) {
+        // conservative, as pass 2a: pairs of the env at least as close as the farthest candidate (penetrating or not) of any of its feet
+        const unsigned sv0 = cm[0], sv1 = cm[1], sv2 = cm[2], sv3 = cm[3];
+        float kmax = -3.0e38f;
+        for (;;) {
+          if (__ballot((cm[0] | cm[1] | cm[2] | cm[3]) != 0u) == 0ull) break;
+          const int b = pop();
+          const float4 A = sh_box[(b >= 0 ? b : 0) * kEnvsPerWave + quad];
+          kmax = b >= 0 ? fmaxf(kmax, norm(v3(A.x, A.y, A.z) - s.footc) - keyC) : kmax;
+        }
+        cm[0] = sv0; cm[1] = sv1; cm[2] = sv2; cm[3] = sv3;
+        kmax = quad_max(kmax);
+        const float thr = (kmax + keyC) * 1.000002f + 1e-7f, thr2 = kmax > -1.0e38f ? thr * thr : -1.f;
+        int cnt = 0;
+#pragma unroll 1
+        for (int b = 0; b < nbox; b++) {
+          const float4 A = sh_box[b * kEnvsPerWave + quad];
+          const V3 dv = v3(A.x, A.y, A.z) - s.footc;
+          cnt += dot(dv, dv) <= thr2 ? 1 : 0;
+        }
+        cutting = quad_sum_i(cnt) > maxp;
+      }
+      auto ordkey = [&](const QPen& p) { return broad ? packed_key(p.key, p.idx) : (unsigned long long)(unsigned)p.idx; };
+      int npenetr = 0;
+      for (;;) {
+        if (__ballot((cm[0] | cm[1] | cm[2] | cm[3]) != 0u) == 0ull) break;
+        const int b = pop();
+        const bool have = b >= 0;
+        TerrainBox tb = boxes[have ? b : 0];
+        float nd; V3 pw, nw;
+        sphere_box(s.footc, rad, tb, nd, pw, nw);
+        QPen pp; pp.dist = have ? nd : 1.f; pp.key = norm(v3(tb.px, tb.py, tb.pz) - s.footc) - keyC; pp.idx = l * nbox + (have ? b : 0);
+        const bool penn = pp.dist < 0.f;
+        npenetr += penn ? 1 : 0;
+        bool alive = penn;
+        if (__ballot(penn & cutting) != 0ull) {
+          // exact broad-phase rank of the four legs' current pairs: pairs of the env that sort before them by (key, pair index)
+          const unsigned long long pk = penn ? packed_key(pp.key, pp.idx) : 0ull;
+          const int plo = (int)(unsigned)pk, phi = (int)(unsigned)(pk >> 32);
+          auto wide = [](int hi, int lo) { return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo; };
+          const unsigned long long c0 = wide(quad_bcast<0>(phi), quad_bcast<0>(plo)), c1 = wide(quad_bcast<1>(phi), quad_bcast<1>(plo));
+          const unsigned long long c2 = wide(quad_bcast<2>(phi), quad_bcast<2>(plo)), c3 = wide(quad_bcast<3>(phi), quad_bcast<3>(plo));
+          int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+#pragma unroll 1
+          for (int bb = 0; bb < nbox; bb++) {
+            const float4 A = sh_box[bb * kEnvsPerWave + quad];
+            const unsigned long long q = packed_key(norm(v3(A.x, A.y, A.z) - s.footc) - keyC, l * nbox + bb);
+            r0 += q < c0 ? 1 : 0; r1 += q < c1 ? 1 : 0; r2 += q < c2 ? 1 : 0; r3 += q < c3 ? 1 : 0;
+          }
+          r0 = quad_sum_i(r0); r1 = quad_sum_i(r1); r2 = quad_sum_i(r2); r3 = quad_sum_i(r3);
+          const int rk = l == 0 ? r0 : (l == 1 ? r1 : (l == 2 ? r2 : r3));
+          alive = penn & !(cutting & (rk >= maxp));
+        }
+        // the table's last entry in MJX's order, and whether the newcomer sorts before it
+        const bool room = npen < kMaxPenQ;
+        int wi = 0; float wd = pen[0].dist; unsigned long long wk = ordkey(pen[0]);
+#pragma unroll
+        for (int i = 1; i < kMaxPenQ; i++) {
+          const unsigned long long ki = ordkey(pen[i]);
+          const bool later = (pen[i].dist > wd) | ((pen[i].dist == wd) & (ki > wk));
+          wd = later ? pen[i].dist : wd; wk = later ? ki : wk; wi = later ? i : wi;
+        }
+        const bool better = (pp.dist < wd) | ((pp.dist == wd) & (ordkey(pp) < wk));
+        const bool put = alive & (room | better);
+        const bool swap = put & !room;
+        // a full table loses entry wi: the entries behind it move up (registers by selects, point / normal in the slot records) ...
+#pragma unroll
+        for (int i = 0; i + 1 < kMaxPenQ; i++) {
+          const bool mv = swap & (i >= wi);
+          pen[i].dist = mv ? pen[i + 1].dist : pen[i].dist; pen[i].key = mv ? pen[i + 1].key : pen[i].key; pen[i].idx = mv ? pen[i + 1].idx : pen[i].idx;
+          if (mv) {
+#pragma unroll
+            for (int f = 7; f <= 12; f++) { const float v = slots.at(i + 1, f); slots.at(i, f) = v; }
+          }
+        }
+        // ... and the newcomer goes behind them (it has the highest pair index so far)
+        const int at = room ? npen : kMaxPenQ - 1;
+#pragma unroll
+        for (int i = 0; i < kMaxPenQ; i++) { const bool hit = put & (i == at); pen[i].dist = hit ? pp.dist : pen[i].dist; pen[i].key = hit ? pp.key : pen[i].key; pen[i].idx = hit ? pp.idx : pen[i].idx; }
+        if (put) park(at, pw, nw);
+        npen += (put & room) ? 1 : 0;
+      }
+      s.pen_overflow |= npenetr > kMaxPenQ;
     }
     PG_TICK(s, 13);
     if (__ballot(npen > 0) == 0ull) return;

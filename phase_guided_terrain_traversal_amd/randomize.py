@@ -17,6 +17,12 @@ Distributions are the reference's, including its quirks:
 Streams: ONE numpy Philox stream per seed in which env e owns a fixed block of 280 outputs (vectorised: no per-env Python
 loop), so a shard draws the same numbers as the full batch
 (JAX threefry equivalence is not required).
+
+Terrain variants are drawn per env like the reference's ``rand_idx`` (randomize.py:97-101) and then, by default, handed out in ascending
+order within every block of ``VARIANT_GROUP`` consecutive GLOBAL env ids (`group_variants`): the multiset of draws of a block is untouched
+(env ids are exchangeable labels and every other per-env draw is independent of the variant), but neighbouring envs now stand on the same
+variant, and since ``physics_kernel`` hands each XCD a contiguous range of envs, each XCD's L2 pulls ~1/8 of the terrain table per launch
+instead of all of it (profiles/hbm_traffic.json).  The order depends on global ids and the job's total only, so shards stay invariant.
 """
 from __future__ import annotations
 
@@ -31,6 +37,7 @@ from . import abi
 # env id alone).  280 doubles = 70 Philox4x64 counter steps per env.
 _D_FLOOR, _D_BOXF, _D_FLOSS, _D_ARM, _D_IPOS, _D_MASS, _D_BASEM, _D_QPOS0, _D_DAMP, _D_GAIN, _D_VAR = 0, 1, 101, 113, 125, 128, 242, 243, 255, 267, 279
 _DRAWS = 280
+VARIANT_GROUP = 4096        # global env ids per block within which the variant draws are handed out in ascending order
 
 
 def _uniform_blocks(seed: int, first_env: int, n: int) -> np.ndarray:
@@ -41,9 +48,30 @@ def _uniform_blocks(seed: int, first_env: int, n: int) -> np.ndarray:
     return np.random.Generator(bg).random((n, _DRAWS))
 
 
+def _variant_draws(seed: int, first_env: int, n: int, T: int) -> np.ndarray:
+    """randint(0, T) per global env id (randomize.py:97-100), in draw order"""
+    U = _uniform_blocks(seed, first_env, n)[:, _D_VAR]
+    return np.minimum((U * T).astype(np.int64), T - 1).astype(np.int32)
+
+
+def grouped_variants(seed: int, first_env: int, n: int, T: int, total_envs: Optional[int] = None) -> np.ndarray:
+    """the draws of `_variant_draws`, ascending within each block of VARIANT_GROUP global env ids (the last block ends at `total_envs`, the
+    job's env count - default: this shard is the job's last): a permutation of every block's own draws, a function of global ids alone"""
+    total = first_env + n if total_envs is None else int(total_envs)
+    assert first_env + n <= total, "shard reaches beyond the job's env count"
+    g0 = (first_env // VARIANT_GROUP) * VARIANT_GROUP
+    g1 = min(-(-(first_env + n) // VARIANT_GROUP) * VARIANT_GROUP, total)
+    v = _variant_draws(seed, g0, g1 - g0, T)
+    for b in range(0, g1 - g0, VARIANT_GROUP):
+        v[b:b + VARIANT_GROUP] = np.sort(v[b:b + VARIANT_GROUP], kind="stable")
+    return v[first_env - g0:first_env - g0 + n]
+
+
 def domain_randomize(model: Dict[str, Any], num_envs: int, seed: int = 0, terrain: Optional[np.ndarray] = None,
-                     env_id_offset: int = 0, enable: bool = True, _frac: Optional[float] = None) -> Dict[str, np.ndarray]:
-    """`_frac` (tests only): every draw returns lo + _frac * (hi - lo) instead of a Philox sample, which is how
+                     env_id_offset: int = 0, enable: bool = True, _frac: Optional[float] = None,
+                     group_variants: bool = True, total_envs: Optional[int] = None) -> Dict[str, np.ndarray]:
+    """`group_variants` / `total_envs`: see the module text (`total_envs` = env count of the whole job when this call draws one shard of it).
+    `_frac` (tests only): every draw returns lo + _frac * (hi - lo) instead of a Philox sample, which is how
     tests/golden/domain_randomize.npz was recorded from the reference's own functions."""
     n = int(num_envs)
     P = np.zeros((abi.NPARAM, n), dtype=np.float32)
@@ -78,7 +106,12 @@ def domain_randomize(model: Dict[str, Any], num_envs: int, seed: int = 0, terrai
     out = {"params": P, "variant": np.zeros(n, dtype=np.int32)}
     if nbox:
         # randint(0, T) (randomize.py:97-100); the recorded fixture pins it to int(f (T - 1))
-        out["variant"] = (np.minimum((U[:, _D_VAR] * T).astype(np.int64), T - 1) if _frac is None else np.full(n, int(_frac * (T - 1)))).astype(np.int32)
+        if _frac is not None:
+            out["variant"] = np.full(n, int(_frac * (T - 1)), dtype=np.int32)
+        elif group_variants:
+            out["variant"] = grouped_variants(seed, env_id_offset, n, T, total_envs)
+        else:
+            out["variant"] = np.minimum((U[:, _D_VAR] * T).astype(np.int64), T - 1).astype(np.int32)
         bf = np.full((abi.MAX_BOX, n), float(model["box_friction"][0]), dtype=np.float32)
         if enable:
             bf[:nbox] = u(0.4, 1.0, _D_BOXF, nbox).T

@@ -64,6 +64,25 @@ def test_dr_is_shard_invariant():
     assert np.array_equal(full["box_friction"][:, 16:24], part["box_friction"])
 
 
+def test_grouped_variants_keep_the_draws_and_the_shards():
+    """variants are handed out in ascending order within blocks of VARIANT_GROUP global env ids: every block keeps the multiset of its own
+    per-env draws (go2/randomize.py:97-101 draws rand_idx per env), and any shard of the job reads its slice of the same global labelling"""
+    from phase_guided_terrain_traversal_amd import randomize
+    m = mjcf.load_model("stairs")
+    terr = np.load(os.path.join(os.path.dirname(mjcf.__file__), "assets", "terrains", "level4.npy"))
+    G, total = randomize.VARIANT_GROUP, 2 * randomize.VARIANT_GROUP + 1000
+    full = domain_randomize(m, total, seed=7, terrain=terr)
+    raw = domain_randomize(m, total, seed=7, terrain=terr, group_variants=False)
+    assert np.array_equal(full["params"], raw["params"]) and np.array_equal(full["box_friction"], raw["box_friction"])
+    for b in range(0, total, G):
+        assert np.array_equal(full["variant"][b:b + G], np.sort(raw["variant"][b:b + G]))
+    assert len(np.unique(full["variant"][2 * G:])) > 80           # the short last block still spans the table (no truncated sort)
+    for lo, hi in ((0, 1500), (1500, G + 300), (G + 300, 2 * G + 10), (2 * G + 10, total)):
+        part = domain_randomize(m, hi - lo, seed=7, terrain=terr, env_id_offset=lo, total_envs=total)
+        assert np.array_equal(part["variant"], full["variant"][lo:hi]), (lo, hi)
+        assert np.array_equal(part["params"], full["params"][:, lo:hi])
+
+
 def test_gloo_world2_metric_allreduce(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)

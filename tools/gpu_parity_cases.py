@@ -31,7 +31,7 @@ def find(task, n, terrain, steps, ctrl_dt):
         for e in np.nonzero(W & (eg["qpos"] > 1e-4))[0]:
             cases.append(dict(step=k, env=e, state=pre["state"][:, e], istate=pre["istate"][:, e], scan_z=pre["scan_z"][e], action=act[e],
                               variant=hb["variant"][e] if "variant" in hb.arrays else 0, gpu=g["state"][:55, e], o32=hb["state"][:55, e], o64=h64["state"][:55, e],
-                              ni=np.array([g["dbg_niter"][e], hb["dbg_niter"][e], h64["dbg_niter"][e]]), r=np.array([r32[e], r64[e]])))
+                              ni=np.array([g["dbg_niter"][e] & 0xFFFF, hb["dbg_niter"][e], h64["dbg_niter"][e]]), r=np.array([r32[e], r64[e]])))
     env.close()
     return cases
 

@@ -30,7 +30,7 @@ def collect(task, n, terrain, steps, dr=False, autoreset=False, method="pgtt", c
         torch.cuda.synchronize()
         g = {kk: v.cpu().numpy() for kk, v in env.buffers.items()}
         EG.append(P.per_env_errors(g, hb)); EF.append(P.per_env_errors(hb.arrays, h64))
-        NI.append(np.stack([g["dbg_niter"], hb["dbg_niter"], h64["dbg_niter"]]))
+        NI.append(np.stack([g["dbg_niter"] & 0xFFFF, hb["dbg_niter"], h64["dbg_niter"]]))
         FM.append((g["frame"][abi.F_CONTACT:abi.F_CONTACT + 4] != hb["frame"][abi.F_CONTACT:abi.F_CONTACT + 4]).any(0))
         ga, ha = P.active_sets(g["dbg_contact"], g["dbg_dist"]), P.active_sets(hb["dbg_contact"], hb["dbg_dist"])
         SM.append(np.array([a != b for a, b in zip(ga, ha)]))

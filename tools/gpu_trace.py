@@ -16,7 +16,7 @@ buf = np.zeros(65536, np.float32)
 L.pgtt_trace_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
 L.pgtt_trace_read(buf.ctypes.data, buf.size)
 g = {k: v.cpu().numpy() for k, v in env.buffers.items()}
-print(name, "niter gpu", np.bincount(g["dbg_niter"], minlength=6), "cpu", np.bincount(hb["dbg_niter"], minlength=6))
+print(name, "niter gpu", np.bincount(g["dbg_niter"] & 0xFFFF, minlength=6), "cpu", np.bincount(hb["dbg_niter"], minlength=6))
 print("qacc err env0", np.abs(g["state"][37:55, 0] - hb["state"][37:55, 0]).max())
 seg = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 tr = buf.reshape(4, -1, 4)[seg]          # [launch][record][lane]

@@ -46,7 +46,7 @@ def run_training(args):
     lo, hi = shard_range(args.num_envs, rank, world)
     if (hi - lo) * world != args.num_envs:
         raise SystemExit(f"--num_envs {args.num_envs} must be a multiple of the world size {world}")
-    dr = domain_randomize(model, hi - lo, seed=args.index, terrain=terrain, env_id_offset=lo)      # once per env index
+    dr = domain_randomize(model, hi - lo, seed=args.index, terrain=terrain, env_id_offset=lo, total_envs=args.num_envs)      # once per env index
     kw = {"params": torch.from_numpy(dr["params"])}
     if terrain is not None:
         kw.update(variant=torch.from_numpy(dr["variant"]), box_friction=torch.from_numpy(dr["box_friction"]))
