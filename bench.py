@@ -301,8 +301,64 @@ def other_configs(args, local, dev, sync):
                      "wall_over_kernels": ms / (w["physics_ms"] + w["observe_ms"] + w["gemv_ms"]),
                      "roofline_frac_physics": r["roofline"]["frac"], "traffic": r["roofline"]["traffic"], "lane_layout": args.layout,
                      "setup_s": time.perf_counter() - t0 - w["dt"]})
+    rows.append(rollout_row(args, local, dev, sync))
     rows.append(precise_build_row(args))
     return rows
+
+
+def rollout_row(args, local, dev, sync):
+    """the hot path inside the loop its caller runs (training/train.py:135-161 -> Brax generate_unroll): the reference-trained policy177
+    (deploy/policy_net.py:36-71: normalise, 171-512-256-128-24 SiLU MLP, tanh-normal head) SAMPLES an action for every env, the env steps,
+    reward / done / truncation and the finished-episode sums are recorded - four launches per acting step (acting.FusedActor: pgtt_policy_act
+    on fp32 MFMA, physics_kernel, observe_kernel, pgtt_rollout_record), ONE captured HIP graph replayed per step, roll-outs of 20 steps
+    (unroll_length).  Headline workload, same priming discipline.  Never part of `value`."""
+    import copy
+    import torch
+    from phase_guided_terrain_traversal_amd import policy
+    from phase_guided_terrain_traversal_amd.acting import FusedActor
+    a2 = copy.copy(args); a2.workload, a2.envs = "level4", 4096
+    T, steps = REDUCE_EVERY, max(200, args.other_steps)
+    row = {"workload": "rollout", "envs": a2.envs, "what": "policy177 forward + sample + env.step + bookkeeping, one HIP graph per acting step, level4 (N1: caller of the hot path)",
+           "steps": steps, "unroll_length": T, "lane_layout": args.layout, "launches_per_step": 4}
+    try:
+        t0 = time.perf_counter()
+        env, cfg, terrain, task, dr = build_env(a2, 0, 1, local)
+        net = policy.load_policy("policy177", device=f"cuda:{local}")
+        fa = FusedActor(env, T=T, seed=1)
+        fa.load([(l.weight, l.bias) for l in net.layers], net.mean, net.std)
+        env.reset(seed=0)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fa.step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        fa.rewind()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fa.step()
+        fa.rewind()
+
+        def run(k):
+            for i in range(k):
+                g.replay()
+                if (i + 1) % T == 0:
+                    fa.rewind()                     # the learner would consume the [T, N] batch here
+        run(PRIME_STEPS // T * T)
+        fa.episode_sums.zero_()
+        sync()
+        t1 = time.perf_counter()
+        run(steps // T * T)
+        sync()
+        dt = time.perf_counter() - t1
+        n_steps = steps // T * T
+        es = fa.episode_sums.cpu().numpy()
+        row.update(value=a2.envs * n_steps / dt, unit="env-steps/s", steps=n_steps, ms_per_step=1e3 * dt / n_steps,
+                   episodes_finished=float(es[-1]), mean_episode_length=float(es[-2] / max(es[-1], 1.0)), setup_s=time.perf_counter() - t0 - dt)
+        env.close()
+    except Exception as e:          # a caller-side row must never cost the headline line
+        row["skipped"] = f"{type(e).__name__}: {e}"
+    return row
 
 
 def precise_build_row(args):

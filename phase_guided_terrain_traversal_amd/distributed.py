@@ -9,6 +9,7 @@ same code runs on CPU tensors (used by the world_size-2 tests).
 from __future__ import annotations
 
 import os
+from collections.abc import Mapping
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -51,20 +52,40 @@ def init_from_env(backend: Optional[str] = None, force: bool = False) -> Tuple[i
     return rank, local, world
 
 
-class _Reduced(dict):
-    """result of a reduction: the all-reduced sums; the means are formed when somebody asks for them (a logging step, not every interval)"""
+class _Reduced(Mapping):
+    """result of a reduction: the all-reduced sums [22 metric sums, sum_reward, n_done, n_env_steps] behind the keys `metrics_mean`,
+    `reward_mean`, `done_count`, `env_steps` (and `sums`).  The two means cost a kernel each and only a logging step reads them, so they are
+    formed when first asked for - but they ARE keys: `in`, `.get()`, iteration and `**` see the same five whichever reduction returned the object."""
 
-    def __missing__(self, key):
-        buf = self["sums"]
-        n = buf[abi.NMETRIC + 2].clamp(min=1.0)
-        if key == "metrics_mean":
-            v = buf[:abi.NMETRIC] / n
+    KEYS = ("metrics_mean", "reward_mean", "done_count", "env_steps", "sums")
+
+    def __init__(self, sums: torch.Tensor):
+        self._sums, self._cache = sums, {}
+
+    def __getitem__(self, key):
+        if key in self._cache:
+            return self._cache[key]
+        buf = self._sums
+        if key == "sums":
+            v = buf
+        elif key == "done_count":
+            v = buf[abi.NMETRIC + 1]
+        elif key == "env_steps":
+            v = buf[abi.NMETRIC + 2]
+        elif key == "metrics_mean":
+            v = buf[:abi.NMETRIC] / buf[abi.NMETRIC + 2].clamp(min=1.0)
         elif key == "reward_mean":
-            v = buf[abi.NMETRIC] / n
+            v = buf[abi.NMETRIC] / buf[abi.NMETRIC + 2].clamp(min=1.0)
         else:
             raise KeyError(key)
-        self[key] = v
+        self._cache[key] = v
         return v
+
+    def __iter__(self):
+        return iter(self.KEYS)
+
+    def __len__(self):
+        return len(self.KEYS)
 
 
 class MetricReducer:
@@ -120,7 +141,7 @@ class MetricReducer:
         env.interval_reduce(buf, float(env_steps))
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        return _Reduced(sums=buf, done_count=buf[abi.NMETRIC + 1], env_steps=buf[abi.NMETRIC + 2])
+        return _Reduced(buf)
 
     def reduce(self) -> Dict[str, torch.Tensor]:
         """Sum over ranks (one RCCL all-reduce), reset the local accumulator, return global means."""
@@ -131,6 +152,4 @@ class MetricReducer:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         self.acc.zero_()
         self._dirty = False
-        n = buf[abi.NMETRIC + 2].clamp(min=1.0)
-        return {"metrics_mean": buf[:abi.NMETRIC] / n, "reward_mean": buf[abi.NMETRIC] / n,
-                "done_count": buf[abi.NMETRIC + 1], "env_steps": buf[abi.NMETRIC + 2]}
+        return _Reduced(buf)

@@ -176,7 +176,10 @@ class Joystick:
     def interval_reduce(self, out: torch.Tensor, env_steps: float = 0.0, accumulate: bool = False) -> None:
         """out[k] (+)= sum over the envs of buffers['interval_sums'][k] (k < NMETRIC + 2), out[NMETRIC + 2] (+)= env_steps, the rows cleared:
         one launch (pgtt_interval_reduce)"""
-        assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == abi.NMETRIC + 3 and out.device == self.buffers["interval_sums"].device
+        if "interval_sums" not in self.buffers:
+            raise native.PgttError("interval_reduce: this env keeps no interval sums - create it with Joystick(..., interval_sums=True)")
+        if not (out.dtype == torch.float32 and out.is_contiguous() and out.numel() == abi.NMETRIC + 3 and out.device == self.buffers["interval_sums"].device):
+            raise ValueError(f"interval_reduce: `out` must be {abi.NMETRIC + 3} contiguous float32 values on {self.buffers['interval_sums'].device}")
         native.check(self._lib.pgtt_interval_reduce(self._h, out.data_ptr(), float(env_steps), int(accumulate), self._stream()))
 
     def set_test_overrides(self, rng_value: Optional[float] = None, scan_preset: bool = False) -> None:

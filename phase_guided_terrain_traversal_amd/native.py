@@ -15,7 +15,8 @@ _LIB: Optional[C.CDLL] = None
 EXPORTS = ["pgtt_create", "pgtt_destroy", "pgtt_set_terrain", "pgtt_bind", "pgtt_reset", "pgtt_step",
            "pgtt_physics", "pgtt_observe", "pgtt_scan", "pgtt_interval_reduce", "pgtt_set_test_overrides", "pgtt_enable_timing", "pgtt_last_kernel_ms", "pgtt_kernel_ms_mean",
            "pgtt_obs_dims", "pgtt_sizeof_model", "pgtt_sizeof_config", "pgtt_sizeof_buffers", "pgtt_version", "pgtt_last_error"]
-TRAIN_EXPORTS = ["pgtt_ppo_policy_loss", "pgtt_ppo_linear_backward"]      # include/pgtt_train.h: trainer helpers, not the env boundary
+TRAIN_EXPORTS = ["pgtt_ppo_policy_loss", "pgtt_ppo_linear_backward", "pgtt_policy_act", "pgtt_policy_packed_floats", "pgtt_rollout_record",
+                 "pgtt_sizeof_policy_act_args", "pgtt_sizeof_rollout_record_args"]      # include/pgtt_train.h: trainer helpers, not the env boundary
 
 
 class PgttError(RuntimeError):

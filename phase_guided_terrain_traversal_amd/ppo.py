@@ -212,19 +212,31 @@ class PPOConfig:
 
 
 class _Actor:
-    """T acting steps into preallocated [T, N, ...] storage.  One acting step (normalise, policy MLP, sample, tanh,
-    env.step = two HIP kernels, bookkeeping: ~60 small launches) is captured ONCE in a HIP graph and replayed: the
-    acting loop is launch-bound, not compute-bound.  The write row is a device-side counter, so one graph serves every t."""
+    """T acting steps into preallocated [T, N, ...] storage, one acting step captured ONCE in a HIP graph and replayed (the write row
+    is a device-side counter, so one graph serves every t).
 
-    def __init__(self, env, model, norm_s, T, cfg, L, acc, use_graph=True):
+    On a GPU the step is FOUR launches (round 4, acting.FusedActor): pgtt_policy_act (normalise, the 171-512-256-128-24 SiLU MLP on
+    fp32 MFMA, tanh-normal sample, log-probability, tanh, the observation / action rows of the storage), the two kernels of env.step,
+    pgtt_rollout_record (reward / done / truncation rows, finished-episode sums).  PGTT_PPO_ACT_FUSED=0 - and any env that is not a
+    Joystick on a GPU (the CPU stub of the gloo tests) - takes the PyTorch-op form of the same step: ~60 small launches, library GEMMs."""
+
+    def __init__(self, env, model, norm_s, T, cfg, L, acc, use_graph=True, ep_sums=None):
         self.env, self.model, self.norm_s, self.T, self.cfg, self.L = env, model, norm_s, T, cfg, L
         self.ep_ret_sum, self.ep_len_sum, self.ep_cnt, self.ep_metric_sum = acc
         dev, n = env.device, env.num_envs
         od, pd = env.observation_size["state"], env.observation_size["privileged_state"]
         z = lambda *sh: torch.zeros(*sh, device=dev)
-        self.S = {"obs": z(T, n, od), "priv": z(T, n, pd), "u": z(T, n, abi.NU), "logp": z(T, n), "rew": z(T, n), "done": z(T, n), "trunc": z(T, n)}
-        self.t = torch.zeros(1, dtype=torch.long, device=dev)
-        self.act = z(n, abi.NU)
+        self.fused = None
+        if (torch.device(dev).type == "cuda" and ep_sums is not None and hasattr(env, "env_id_offset") and os.environ.get("PGTT_PPO_ACT_FUSED", "1") != "0"
+                and tuple(m.out_features for m in model.policy if isinstance(m, nn.Linear)) == (512, 256, 128, 2 * abi.NU)):
+            from .acting import FusedActor
+            self.fused = FusedActor(env, T, seed=cfg.seed + 7919 * _world()[1], reward_scaling=cfg.reward_scaling, episode_sums=ep_sums)
+            self.S, self.act, self.t = self.fused.storage, self.fused.action, self.fused.counters[:1]
+            self.fused.load_sequential(model.policy, norm_s.mean, norm_s.std)
+        else:
+            self.S = {"obs": z(T, n, od), "priv": z(T, n, pd), "u": z(T, n, abi.NU), "logp": z(T, n), "rew": z(T, n), "done": z(T, n), "trunc": z(T, n)}
+            self.t = torch.zeros(1, dtype=torch.long, device=dev)
+            self.act = z(n, abi.NU)
         self.graph = None
         if use_graph:
             try:
@@ -246,6 +258,9 @@ class _Actor:
                 self.t.zero_()
 
     def _step(self):
+        if self.fused is not None:
+            self.fused.step()
+            return
         env, S, t, cfg = self.env, self.S, self.t, self.cfg
         o, p = env.buffers["obs_state"], env.buffers["obs_priv"]
         loc, scale = self.model.dist(self.norm_s(o))
@@ -264,6 +279,8 @@ class _Actor:
 
     def rollout(self):
         self.t.zero_()
+        if self.fused is not None:          # the learner has moved the weights and the statistics since the last roll-out: repack (in place)
+            self.fused.load_sequential(self.model.policy, self.norm_s.mean, self.norm_s.std)
         for _ in range(self.T):
             if self.graph is not None:
                 self.graph.replay()
@@ -440,13 +457,14 @@ def train(env, cfg: PPOConfig, progress_fn: Optional[Callable[[int, Dict[str, fl
     obs = env.reset(seed=cfg.seed)
     actor, learner = None, None
     history, env_steps, t_env, t_sgd = [], 0, 0.0, 0.0
-    ep_ret_sum = torch.zeros((), device=dev); ep_len_sum = torch.zeros((), device=dev); ep_cnt = torch.zeros((), device=dev)
-    ep_metric_sum = torch.zeros(abi.NMETRIC, device=dev)
+    # finished-episode sums since the last evaluation, ONE block [22 metric sums; return; length; count] (the layout pgtt_rollout_record adds to)
+    ep_sums = torch.zeros(abi.NMETRIC + 3, device=dev)
+    ep_metric_sum, ep_ret_sum, ep_len_sum, ep_cnt = ep_sums[:abi.NMETRIC], ep_sums[abi.NMETRIC], ep_sums[abi.NMETRIC + 1], ep_sums[abi.NMETRIC + 2]
     for it in range(iters):
         t0 = time.perf_counter()
         with torch.no_grad():
             if actor is None:
-                actor = _Actor(env, model, norm_s, T, cfg, L, acc=(ep_ret_sum, ep_len_sum, ep_cnt, ep_metric_sum), use_graph=use_graph)
+                actor = _Actor(env, model, norm_s, T, cfg, L, acc=(ep_ret_sum, ep_len_sum, ep_cnt, ep_metric_sum), use_graph=use_graph, ep_sums=ep_sums)
             batch = actor.rollout()
             obs = env._obs()
             last_priv = obs["privileged_state"].clone()
@@ -491,7 +509,7 @@ def train(env, cfg: PPOConfig, progress_fn: Optional[Callable[[int, Dict[str, fl
             for i, k in enumerate(abi.REWARD_KEYS):
                 m[f"eval/episode_reward/{k}"] = log[3 + i] / c
             history.append((env_steps, m))
-            ep_ret_sum.zero_(); ep_len_sum.zero_(); ep_cnt.zero_(); ep_metric_sum.zero_()
+            ep_sums.zero_()
             if policy_params_fn is not None and rank == 0:
                 policy_params_fn(env_steps, checkpoint(model, norm_s, norm_p))
             if progress_fn is not None and progress_fn(env_steps, m):
