@@ -168,6 +168,7 @@ int pgtt_sizeof_buffers(void) { return (int)sizeof(PgttBuffers); }
 int pgtt_create(const PgttConfig* cfg, const PgttModel* model, int device, int num_envs, pgtt_handle* out) {
   if (!cfg || !model || !out) return fail(PGTT_E_ARG, "pgtt_create: null argument");
   if (num_envs <= 0) return fail(PGTT_E_ARG, "pgtt_create: num_envs must be positive");
+  if (num_envs > (1 << 22)) return fail(PGTT_E_ARG, "pgtt_create: at most 4 194 304 envs per handle (the step kernel addresses its rows through 32-bit byte offsets)");
   if (cfg->n_substeps < 1 || cfg->n_substeps > 64) return fail(PGTT_E_ARG, "pgtt_create: n_substeps out of range");
   if (cfg->method != PGTT_METHOD_PGTT && cfg->method != PGTT_METHOD_BASELINE) return fail(PGTT_E_ARG, "pgtt_create: unknown method");
   if (cfg->lane_layout != PGTT_LAYOUT_AUTO && cfg->lane_layout != PGTT_LAYOUT_QUAD && cfg->lane_layout != PGTT_LAYOUT_OCT && cfg->lane_layout != PGTT_LAYOUT_HEX)

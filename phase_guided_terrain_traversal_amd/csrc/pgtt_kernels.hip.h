@@ -133,20 +133,21 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   s.tlast = t0_cyc;
 #endif
 #pragma unroll
-  for (int i = 0; i < 7; i++) s.qb[i] = S[(PGTT_S_QPOS + i) * (long)N + e];
+  for (int i = 0; i < 7; i++) s.qb[i] = PG_ROW(S, PGTT_S_QPOS + i, N, e);
 #pragma unroll
-  for (int i = 0; i < 6; i++) { s.vb[i] = S[(PGTT_S_QVEL + i) * (long)N + e]; s.wb[i] = S[(PGTT_S_QWARM + i) * (long)N + e]; }
+  for (int i = 0; i < 6; i++) { s.vb[i] = PG_ROW(S, PGTT_S_QVEL + i, N, e); s.wb[i] = PG_ROW(S, PGTT_S_QWARM + i, N, e); }
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     const int j = 3 * l + k, ac = 3 * (l ^ 1) + k;     // joint index, actuator index driving it
-    s.ql[k] = S[(PGTT_S_QPOS + 7 + j) * (long)N + e];
-    s.vl[k] = S[(PGTT_S_QVEL + 6 + j) * (long)N + e];
-    s.wl[k] = S[(PGTT_S_QWARM + 6 + j) * (long)N + e];
-    if (MODE == MODE_STEP) s.ctrl[k] = gm->key_qpos[7 + ac] + action[(long)e * 12 + ac] * cfg->action_scale;
-    else s.ctrl[k] = S[(PGTT_S_QPOS + 7 + ac) * (long)N + e];          // mjx_env.init(ctrl = qpos[7:])
+    s.ql[k] = PG_ROW(S, PGTT_S_QPOS + 7 + j, N, e);
+    s.vl[k] = PG_ROW(S, PGTT_S_QVEL + 6 + j, N, e);
+    s.wl[k] = PG_ROW(S, PGTT_S_QWARM + 6 + j, N, e);
+    if (MODE == MODE_STEP) s.ctrl[k] = gm->key_qpos[7 + ac] + PG_REC(action, e, 12, ac) * cfg->action_scale;
+    else s.ctrl[k] = PG_ROW(S, PGTT_S_QPOS + 7 + ac, N, e);          // mjx_env.init(ctrl = qpos[7:])
   }
   const TerrainBox* boxes = nullptr;
   const uint4* grid_v = nullptr;
+  unsigned box0 = 0u, cell0 = 0u;       // PG_ADDR32: first box / grid cell of the env's variant as 32-bit element indices from the tables' bases
   int nbox = 0;
   // LDS staging of the env's terrain variant: centre + bounding radius of its <=100 boxes (read 2 x 4 substeps
   // by the broad phase), and a per-lane column for the broad-phase keys of the own foot
@@ -156,11 +157,16 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   const int quad = lane_env();                         // env within the wave
   const BoxSlots slots{sh_con, lane_col()};
   if (HAS_TERRAIN) {
+#if PG_ADDR32
+    boxes = a.terrain; grid_v = a.grid;
+    box0 = (unsigned)variant * (unsigned)a.B; cell0 = (unsigned)variant * (unsigned)(kGridG * kGridG);
+#else
     boxes = a.terrain + (long)variant * a.B;
     grid_v = a.grid + (long)variant * (kGridG * kGridG);
+#endif
     nbox = a.B;
     for (int b = lane_in_env(); b < nbox; b += 4 * kSubs) {
-      const TerrainBox* tb = boxes + b;
+      const TerrainBox* tb = PG_ADDR32 ? &pg_at(boxes, box0 + (unsigned)b) : boxes + b;
       sh_box[b * kEnvsPerWave + quad] = make_float4(tb->px, tb->py, tb->pz, tb->hx);
       sh_box2[b * kEnvsPerWave + quad] = make_float2(tb->hy, tb->hz);
     }
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
     PG_TICK(s, 9);
     ph.kinematics();
     PG_TICK(s, 0);
-    if (HAS_TERRAIN) ph.collide(boxes, nbox, sh_box, sh_box2, slots, quad, grid_v, a.grid_E, a.grid_inv); else s.nbox = 0;
+    if (HAS_TERRAIN) ph.collide(boxes, box0, nbox, sh_box, sh_box2, slots, quad, grid_v, cell0, a.grid_E, a.grid_inv); else s.nbox = 0;
     PG_TICK(s, 16);
     ph.inertia();
     PG_TICK(s, 0);
@@ -213,8 +219,8 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
       for (int k = 0; k < 3; k++) cacc = cacc + s.cddr[k] * s.vb[3 + k];
       V3 a0 = mtmul(s.R0, cacc.l - cross(dif, cacc.a)) + cross(gyro, llin);
       acc0[0] = a0.x; acc0[1] = a0.y; acc0[2] = a0.z;
-      float* __restrict__ Ho = a.handover_w + (long)ee * kHandover + HO_FRAME;      // MODE_STEP: the same values, env-major, for this step's observe launch
-      auto put1 = [&](int row, float v) { Fr[row * (long)N + ee] = v; if (MODE == MODE_STEP) Ho[row] = v; };
+      float* __restrict__ Ho = &PG_REC(a.handover_w, ee, kHandover, HO_FRAME);      // MODE_STEP: the same values, env-major, for this step's observe launch
+      auto put1 = [&](int row, float v) { PG_ROW(Fr, row, N, ee) = v; if (MODE == MODE_STEP) Ho[row] = v; };
       auto put3 = [&](int row, V3 v) { put1(row, v.x); put1(row + 1, v.y); put1(row + 2, v.z); };
       if (lead) {
         put3(PGTT_F_GYRO, gyro); put3(PGTT_F_GLOBAL_LINVEL, glin); put3(PGTT_F_GLOBAL_ANGVEL, w); put3(PGTT_F_LOCAL_LINVEL, llin);
@@ -271,8 +277,8 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
         float v = acc0[r];
 #pragma unroll
         for (int k = 0; k < 6; k++) v += accA[r][k] * s.qacc_b[k];
-        Fr[(PGTT_F_ACCEL + r) * (long)N + ee] = v;
-        if (MODE == MODE_STEP) a.handover_w[(long)ee * kHandover + HO_FRAME + PGTT_F_ACCEL + r] = v;
+        PG_ROW(Fr, PGTT_F_ACCEL + r, N, ee) = v;
+        if (MODE == MODE_STEP) PG_REC(a.handover_w, ee, kHandover, HO_FRAME + PGTT_F_ACCEL + r) = v;
       }
       if (a.buf.dbg_niter) a.buf.dbg_niter[ee] = s.niter_max | (pen_ovf > 0 ? PGTT_DBG_PEN_OVERFLOW : 0);
     }
@@ -325,34 +331,39 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   // The compiler would otherwise keep the ~50 row addresses formed for the loads at the top alive (spilled to scratch)
   // until these stores: an opaque copy of the env index makes it re-form them here (one mad each).
   asm volatile("" : "+v"(e));
+#if PG_ADDR32
+  int lq = l; asm volatile("" : "+v"(lq));      // ... and of the leg index: the per-leg row offsets (3 l + k) N + e are formed again as well
+#else
+  const int lq = l;
+#endif
   if (MODE == MODE_STEP || a.write_qpos) {
 #pragma unroll
-    for (int i = 0; i < 7; i++) S[(PGTT_S_QPOS + i) * (long)N + e] = s.qb[i];
+    for (int i = 0; i < 7; i++) PG_ROW(S, PGTT_S_QPOS + i, N, e) = s.qb[i];
 #pragma unroll
-    for (int k = 0; k < 3; k++) S[(PGTT_S_QPOS + 7 + 3 * l + k) * (long)N + e] = s.ql[k];
+    for (int k = 0; k < 3; k++) PG_ROW(S, PGTT_S_QPOS + 7 + 3 * lq + k, N, e) = s.ql[k];
   }
   if (MODE == MODE_STEP) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) S[(PGTT_S_QVEL + i) * (long)N + e] = s.vb[i];
+    for (int i = 0; i < 6; i++) PG_ROW(S, PGTT_S_QVEL + i, N, e) = s.vb[i];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      S[(PGTT_S_QVEL + 6 + 3 * l + k) * (long)N + e] = s.vl[k];
-      S[(PGTT_S_MOTOR_TARGETS + 3 * (l ^ 1) + k) * (long)N + e] = s.ctrl[k];
+      PG_ROW(S, PGTT_S_QVEL + 6 + 3 * lq + k, N, e) = s.vl[k];
+      PG_ROW(S, PGTT_S_MOTOR_TARGETS + 3 * (lq ^ 1) + k, N, e) = s.ctrl[k];
     }
-    float* __restrict__ Ho = a.handover_w + (long)e * kHandover;
+    float* __restrict__ Ho = &PG_REC(a.handover_w, e, kHandover, 0);
 #pragma unroll
     for (int i = 0; i < 7; i++) Ho[HO_QPOS + i] = s.qb[i];
 #pragma unroll
     for (int i = 0; i < 6; i++) Ho[HO_QVEL + i] = s.vb[i];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      Ho[HO_QPOS + 7 + 3 * l + k] = s.ql[k]; Ho[HO_QVEL + 6 + 3 * l + k] = s.vl[k]; Ho[HO_MOTOR + 3 * (l ^ 1) + k] = s.ctrl[k];
+      Ho[HO_QPOS + 7 + 3 * lq + k] = s.ql[k]; Ho[HO_QVEL + 6 + 3 * lq + k] = s.vl[k]; Ho[HO_MOTOR + 3 * (lq ^ 1) + k] = s.ctrl[k];
     }
   }
 #pragma unroll
-  for (int i = 0; i < 6; i++) S[(PGTT_S_QWARM + i) * (long)N + e] = s.wb[i];
+  for (int i = 0; i < 6; i++) PG_ROW(S, PGTT_S_QWARM + i, N, e) = s.wb[i];
 #pragma unroll
-  for (int k = 0; k < 3; k++) S[(PGTT_S_QWARM + 6 + 3 * l + k) * (long)N + e] = s.wl[k];
+  for (int k = 0; k < 3; k++) PG_ROW(S, PGTT_S_QWARM + 6 + 3 * lq + k, N, e) = s.wl[k];
 }
 
 // ------------------------------------------------------------------ reset: pose sampling (go2/joystick_pgtt.py:51-70)

@@ -33,6 +33,28 @@ struct TerrainBox {                 // resident terrain table entry (80 B), buil
   float hx, hy, hz, pad;            // half-extents of the WORLD-axis-aligned bounding box (|R| size, rounded up)
 };
 
+// Row `row` of an SoA block [rows][N] for env e (PG_ROW), element i of env e's record in an env-major array (PG_REC).  PG_ADDR32 (quad and oct
+// layouts): through a 32-bit BYTE offset from a wave-uniform base - the form global_load / global_store take as "SGPR base + zero-extended VGPR
+// offset": one register per address instead of a 64-bit pair, and one multiply-add to form it again where it is used.  With 64-bit indices the
+// compiler kept the ~50 row addresses of the prologue alive until the stores (scratch in the oct layout: 18 of its 39 spilled dwords were address
+// pairs) rather than redo a 64-bit multiply.  Valid while 4 * rows * N < 2^32 (pgtt_create refuses more envs).  The hex layout keeps the 64-bit
+// forms it was tuned with: there the change moved code across fp-contraction decisions (results at rounding distance from the build before it)
+// without a gain (round 4).
+#if defined(PG_SUBS) && PG_SUBS == 4
+#define PG_ADDR32 0
+#else
+#define PG_ADDR32 1
+#endif
+template <class T> PG_INL const T& pg_at(const T* base, unsigned idx) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)(idx * (unsigned)sizeof(T))); }
+template <class T> PG_INL T& pg_at(T* base, unsigned idx) { return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (size_t)(idx * (unsigned)sizeof(T))); }
+#if PG_ADDR32
+#define PG_ROW(base, row, N, e) pgtt::pg_at(base, (unsigned)((row) * (N) + (e)))
+#define PG_REC(base, e, stride, i) pgtt::pg_at(base, (unsigned)((e) * (stride) + (i)))
+#else
+#define PG_ROW(base, row, N, e) ((base)[(row) * (long)(N) + (e)])
+#define PG_REC(base, e, stride, i) ((base)[(long)(e) * (stride) + (i)])
+#endif
+
 // ------------------------------------------------------------------ small vector helpers
 struct V3 { float x, y, z; };
 PG_INL V3 v3(float x, float y, float z) { return V3{x, y, z}; }

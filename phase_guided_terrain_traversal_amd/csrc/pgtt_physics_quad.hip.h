@@ -373,19 +373,19 @@ struct QEnvModel {
 template <bool HAS_DR>
 PG_INL void qload_env_model(const PgttModel* __restrict__ m, const float* __restrict__ prm, int N, int e, int l, QEnvModel& em) {
   if (HAS_DR) {
-    em.mass0 = prm[(PGTT_P_BODY_MASS + 0) * (long)N + e];
-    em.base_ipos = v3(prm[(PGTT_P_BASE_IPOS + 0) * (long)N + e], prm[(PGTT_P_BASE_IPOS + 1) * (long)N + e], prm[(PGTT_P_BASE_IPOS + 2) * (long)N + e]);
+    em.mass0 = PG_ROW(prm, PGTT_P_BODY_MASS + 0, N, e);
+    em.base_ipos = v3(PG_ROW(prm, PGTT_P_BASE_IPOS + 0, N, e), PG_ROW(prm, PGTT_P_BASE_IPOS + 1, N, e), PG_ROW(prm, PGTT_P_BASE_IPOS + 2, N, e));
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       const int j = 3 * l + k, a = 3 * (l ^ 1) + k;
-      em.massl[k] = prm[(PGTT_P_BODY_MASS + 1 + j) * (long)N + e];
-      em.qpos0j[k] = prm[(PGTT_P_QPOS0 + j) * (long)N + e];
-      em.armature[k] = prm[(PGTT_P_ARMATURE + j) * (long)N + e];
-      em.damping[k] = prm[(PGTT_P_DAMPING + j) * (long)N + e];
-      em.gain[k] = prm[(PGTT_P_GAIN + a) * (long)N + e];
-      em.bias1[k] = prm[(PGTT_P_BIAS1 + a) * (long)N + e];
+      em.massl[k] = PG_ROW(prm, PGTT_P_BODY_MASS + 1 + j, N, e);
+      em.qpos0j[k] = PG_ROW(prm, PGTT_P_QPOS0 + j, N, e);
+      em.armature[k] = PG_ROW(prm, PGTT_P_ARMATURE + j, N, e);
+      em.damping[k] = PG_ROW(prm, PGTT_P_DAMPING + j, N, e);
+      em.gain[k] = PG_ROW(prm, PGTT_P_GAIN + a, N, e);
+      em.bias1[k] = PG_ROW(prm, PGTT_P_BIAS1 + a, N, e);
     }
-    em.floor_friction = prm[PGTT_P_FLOOR_FRICTION * (long)N + e];
+    em.floor_friction = PG_ROW(prm, PGTT_P_FLOOR_FRICTION, N, e);
   } else {
     em.mass0 = m->body_mass[0];
     em.base_ipos = v3(m->body_ipos[0][0], m->body_ipos[0][1], m->body_ipos[0][2]);
@@ -705,7 +705,7 @@ struct QPhysics {
         cc.on = true; cc.dist = slots.at(k, 0);
         const int b = __float_as_int(slots.at(k, 20));
         cc.box = b;
-        float bf = box_fr ? box_fr[(long)b * N + e] : m->box_friction[0];
+        float bf = box_fr ? (PG_ADDR32 ? PG_ROW(box_fr, b, N, e) : box_fr[(long)b * N + e]) : m->box_friction[0];
         cc.mu = fmaxf(bf, m->foot_friction[0]);
         V3 n, t1, t2;
         make_frame(v3(slots.at(k, 10), slots.at(k, 11), slots.at(k, 12)), n, t1, t2);
@@ -718,8 +718,11 @@ struct QPhysics {
 
   // box collision detection of the own foot (needs the kinematic frames only): leaves, for each of the s.nbox selected
   // pairs, (dist, box, world contact point, world normal) in the slot record; constraint_stage() completes them
-  PG_INL void collide(const TerrainBox* __restrict__ boxes, int nbox, const float4* sh_box, const float2* sh_box2, const BoxSlots& slots, int quad,
-                      const uint4* __restrict__ grid, float grid_E, float grid_inv) {
+  // PG_ADDR32: `boxes` / `grid` are the tables of ALL variants (wave-uniform bases) and box0 / cell0 the first box / cell of the own env's variant
+  // (32-bit element indices: "SGPR base + 32-bit byte offset", see PG_ROW); otherwise they point at the variant's own records and box0 = cell0 = 0
+  PG_INL void collide(const TerrainBox* __restrict__ boxes, unsigned box0, int nbox, const float4* sh_box, const float2* sh_box2, const BoxSlots& slots, int quad,
+                      const uint4* __restrict__ grid, unsigned cell0, float grid_E, float grid_inv) {
+    auto box_rec = [&](int b) -> TerrainBox { if (PG_ADDR32) return pg_at(boxes, box0 + (unsigned)b); return boxes[b]; };
     const float rad = m->foot_radius[l];
     s.nbox = 0;
     if (boxes == nullptr || nbox <= 0) return;
@@ -748,7 +751,7 @@ struct QPhysics {
       const float pad = rad + 1e-5f;
       const float fx = s.footc.x, fy = s.footc.y, fz = s.footc.z;
       const int ix = min(max((int)floorf((fx + grid_E) * grid_inv), 0), kGridG - 1), iy = min(max((int)floorf((fy + grid_E) * grid_inv), 0), kGridG - 1);
-      const uint4 cell = grid[iy * kGridG + ix];
+      const uint4 cell = PG_ADDR32 ? pg_at(grid, cell0 + (unsigned)(iy * kGridG + ix)) : grid[iy * kGridG + ix];
       // hex layout: sub-lane r tests the candidates with box index = r (mod 4); an OR over the sub-lanes gives every lane the mask
       const unsigned own = kSubs == 1 ? 0xFFFFFFFFu : (kSubs == 4 ? (0x11111111u << (threadIdx.x & 3)) : (0x55555555u << (threadIdx.x & 1)));
       unsigned cd[4] = {cell.x & own, cell.y & own, cell.z & own, cell.w & own};
@@ -821,7 +824,7 @@ struct QPhysics {
         b = h1 ? hi : lo;
       }
       const bool have = b >= 0;
-      TerrainBox tb = boxes[have ? b : 0];
+      TerrainBox tb = box_rec(have ? b : 0);
       float nd; V3 pw, nw;
       sphere_box(s.footc, rad, tb, nd, pw, nw);
       QPen pp; pp.dist = have ? nd : 1.f; pp.key = norm(v3(tb.px, tb.py, tb.pz) - s.footc) - keyC; pp.idx = l * nbox + (have ? b : 0);
@@ -890,7 +893,7 @@ struct QPhysics {
         if (__ballot((cm[0] | cm[1] | cm[2] | cm[3]) != 0u) == 0ull) break;
         const int b = pop();
         const bool have = b >= 0;
-        TerrainBox tb = boxes[have ? b : 0];
+        TerrainBox tb = box_rec(have ? b : 0);
         float nd; V3 pw, nw;
         sphere_box(s.footc, rad, tb, nd, pw, nw);
         QPen pp; pp.dist = have ? nd : 1.f; pp.key = norm(v3(tb.px, tb.py, tb.pz) - s.footc) - keyC; pp.idx = l * nbox + (have ? b : 0);
