@@ -70,8 +70,6 @@ typedef struct PgttRolloutRecordArgs {
   float* store_trunc;          /* [T][N] */
   int64_t* counters;           /* device int64[2]: both advanced by one per call */
   float* episode_sums;         /* [PGTT_NMETRIC + 3] += over the envs whose episode ended: 22 metric sums, return, length, count */
-  float* partial;              /* scratch, ceil(N / 256) * (PGTT_NMETRIC + 3) floats */
-  uint32_t* arrivals;          /* scratch, one zero-initialised counter (left at zero) */
   float reward_scaling;
   int32_t num_envs, episode_length;
 } PgttRolloutRecordArgs;

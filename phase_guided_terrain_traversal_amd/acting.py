@@ -32,7 +32,7 @@ class PgttPolicyActArgs(C.Structure):
 
 class PgttRolloutRecordArgs(C.Structure):
     _fields_ = [("reward", _p), ("done", _p), ("ep_steps", _p), ("up_z", _p), ("ep_metrics", _p), ("store_rew", _p), ("store_done", _p),
-                ("store_trunc", _p), ("counters", _p), ("episode_sums", _p), ("partial", _p), ("arrivals", _p), ("reward_scaling", _f),
+                ("store_trunc", _p), ("counters", _p), ("episode_sums", _p), ("reward_scaling", _f),
                 ("num_envs", _i32), ("episode_length", _i32)]
 
 
@@ -78,8 +78,6 @@ class FusedActor:
         self.counters = torch.zeros(2, dtype=torch.int64, device=dev)            # {storage row, draw counter}
         self.episode_sums = z(abi.NMETRIC + 3) if episode_sums is None else episode_sums      # 22 metric sums, return, length, count
         assert self.episode_sums.numel() == abi.NMETRIC + 3 and self.episode_sums.is_contiguous()
-        self._partial = z(-(-n // 256) * (abi.NMETRIC + 3))
-        self._arrivals = torch.zeros(1, dtype=torch.int32, device=dev)
         self.mean, self.std = z(od), torch.ones(od, device=dev)
         dims = (od,) + HIDDEN + (2 * abi.NU,)
         self._w = [z(self._L.pgtt_policy_packed_floats(dims[l], dims[l + 1])) for l in range(4)]
@@ -102,7 +100,7 @@ class FusedActor:
         r.up_z = env.buffers["frame"][abi.F_UPVECTOR + 2].data_ptr()
         r.ep_metrics = env.buffers["ep_metrics"].data_ptr()
         r.store_rew, r.store_done, r.store_trunc = S["rew"].data_ptr(), S["done"].data_ptr(), S["trunc"].data_ptr()
-        r.counters, r.episode_sums, r.partial, r.arrivals = self.counters.data_ptr(), self.episode_sums.data_ptr(), self._partial.data_ptr(), self._arrivals.data_ptr()
+        r.counters, r.episode_sums = self.counters.data_ptr(), self.episode_sums.data_ptr()
         r.reward_scaling, r.num_envs, r.episode_length = float(reward_scaling), n, int(env.config["episode_length"])
         self._rec_args = r
 

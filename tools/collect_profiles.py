@@ -7,7 +7,9 @@ src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
 for a, b in (("driver_cmd_bench.json", "driver_cmd_bench.json"), ("bench_level4.json", "level4_bench.json"), ("bench_flat.json", "flat_bench.json"), ("bench_wfc_dr_8192.json", "wfc_dr_8192_bench.json"),
              ("bench_level4_quad.json", "level4_quad_layout_bench.json"), ("kernel_stats.csv", "level4_kernel_stats.csv"),
              ("bench_wfc_dr_8192_quad.json", "wfc_dr_8192_quad_layout_bench.json"), ("bench_level4_8192.json", "level4_8192_bench.json"),
-             ("bench_level4_32768.json", "level4_32768_bench.json"), ("bench_flat_16384.json", "flat_16384_bench.json")):
+             ("bench_level4_32768.json", "level4_32768_bench.json"), ("bench_flat_16384.json", "flat_16384_bench.json"),
+             ("train_rollout_kernel_stats.csv", "train_rollout_kernel_stats.csv"), ("train_ppo_kernel_stats.csv", "train_ppo_kernel_stats.csv"),
+             ("train_run.txt", "train_run.txt"), ("kt_rollout_bench.json", "train_rollout_bench.json")):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, f"{tag}_{b}"))
 hdr = (f"# rocprofv3 PMC summary, {tag}: {note}; 4096 envs on level4, per-launch means; collected by tools/profile_round.sh\n"
@@ -22,7 +24,7 @@ FETCH_CORR, WRITE_CORR = 2.0, 1.0
 NOTE = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes (profiles/%s_%s), KB * 1024, FETCH x 2 (gfx950 correction, calibrated with "
         "tools/probes/traffic_calib.hip: 131 082 KB reported for 262 144 KB read, WRITE exact).  L2 <-> fabric requests incl. Infinity-Cache hits: the 8 XCD L2s "
         "are not coherent with each other, so each launch reads its state rows (1x) and, per XCD, the records of the terrain variants its envs stand on "
-        "(bench.py labels envs in variant order: ~1/8 of the 0.8 MB table per XCD; in draw order every XCD reads all of it); writes are 16-byte pieces of "
+        "(randomize.domain_randomize hands the per-env variant draws out in ascending order within blocks of 4096 global env ids - the product default since round 4 - so an XCD's range of envs stands on ~1/8 of the 0.8 MB table; in draw order, `--unsorted-variants`, every XCD reads all of it); writes are 16-byte pieces of "
         "64-byte requests per wave (4 envs per wave in the hex layout, 8 in oct).  valu_busy = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES.")
 tp = os.path.join(dst, "hbm_traffic.json")
 t = json.load(open(tp))

@@ -8,6 +8,6 @@ for d in sys.argv[1:]:
         for r in csv.DictReader(open(f)):
             per[(r["Kernel_Name"], r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
         for (k, _, c), v in per.items():
-            acc[(k.split("(")[0], c)].append(v)
+            acc[(k.replace("(anonymous namespace)::", "").split("(")[0], c)].append(v)
 for (k, c), v in sorted(acc.items()):
     print(f"{k[:52]:52s} {c:28s} launches={len(v):4d} mean={sum(v) / len(v):.6g}")

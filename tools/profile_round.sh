@@ -24,6 +24,14 @@ for W in "flat:--workload flat" "wfc_dr_8192:--workload wfc_dr --envs 8192" "lev
   python tools/pmc_summary.py $O/pmc_${T}_FETCH_SIZE $O/pmc_${T}_WRITE_SIZE $O/pmc_${T}_sq > $O/pmc_summary_$T.txt
 done
 cp $O/kt/*kernel_stats.csv $O/kernel_stats.csv
+# round 4: the caller of the hot path on the record - kernel trace of the driver's command WITH its other_configs rows (the 'rollout' row: policy_act_kernel,
+# rollout_record_kernel next to the two env kernels) and of a short train.py run (acting step + PPO update)
+rocprofv3 --kernel-trace --stats -d $O/kt_rollout -o kt --output-format csv -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/kt_rollout_bench.json 2>/dev/null
+cp $O/kt_rollout/*kernel_stats.csv $O/train_rollout_kernel_stats.csv
+rocprofv3 --kernel-trace --stats -d $O/kt_train -o kt --output-format csv -- python train.py --task_name stairs --terrain_file level4 --num_envs 4096 --num_timesteps 1300000 --num_evals 3 --index 904 > $O/train_run.txt 2>&1
+cp $O/kt_train/*kernel_stats.csv $O/train_ppo_kernel_stats.csv; tail -5 $O/train_run.txt
 for f in $O/bench_*.json $O/driver_cmd_bench.json $O/kt_bench.json; do python -c "import sys,json; d=json.load(open('$f')); print('$f', d['value'], d['ms_per_step'], d['kernels_ms'], d.get('wall_over_kernels'))"; done
 grep "physics_kernel<0" $O/pmc_summary.txt | grep -E "FETCH|WRITE|WAVE_CYCLES|WAIT_ANY|ACTIVE_INST_VALU|INSTS_|SQ_WAVES"
 head -3 $O/kernel_stats.csv | cut -c1-150
+# the merged gpurun_out/ may hold 64 MiB: the raw traces stay on the box, the summaries travel
+rm -rf $O/kt $O/kt_rollout $O/kt_train $O/pmc_*/ 2>/dev/null; du -sh $O
