@@ -80,3 +80,22 @@ def test_running_norm_starts_at_unit_std_and_exports():
         pm = policy.PolicyMLP(path)
         loc, _ = model.dist(nm(x))
         assert torch.allclose(pm(x), torch.tanh(loc), atol=1e-5)
+
+
+def test_pack_linear_layout_on_cpu():
+    """acting.pack_linear: [out / 16][in / 16][g][i][s] = W[16 tile + i][16 kb + 4 g + s], zero padding (the order pgtt_policy_act's fp32 MFMA tiles read;
+    include/pgtt_train.h) - and a product against the packed form equals the plain one"""
+    import torch
+    from phase_guided_terrain_traversal_amd.acting import pack_linear
+    torch.manual_seed(0)
+    w, b = torch.randn(24, 171), torch.randn(24)
+    p, pb = pack_linear(w, b)
+    assert p.numel() == 32 * 176 and pb.numel() == 32 and float(pb[24:].abs().sum()) == 0 and torch.equal(pb[:24], b)
+    P = p.view(2, 11, 4, 16, 4)
+    for tile, kb, g, i, s_ in ((0, 0, 0, 0, 0), (1, 10, 2, 7, 2), (0, 5, 3, 15, 3), (1, 10, 3, 7, 3), (1, 3, 1, 9, 0)):
+        n_, k_ = 16 * tile + i, 16 * kb + 4 * g + s_
+        assert float(P[tile, kb, g, i, s_]) == (float(w[n_, k_]) if n_ < 24 and k_ < 171 else 0.0)
+    # unpack = inverse permutation; x W^T through it
+    W2 = P.permute(0, 3, 1, 2, 4).reshape(32, 176)
+    x = torch.randn(5, 171)
+    assert torch.allclose(torch.nn.functional.pad(x, (0, 5)) @ W2.T[:, :24], x @ w.T, atol=1e-5)

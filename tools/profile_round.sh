@@ -28,7 +28,7 @@ cp $O/kt/*kernel_stats.csv $O/kernel_stats.csv
 # rollout_record_kernel next to the two env kernels) and of a short train.py run (acting step + PPO update)
 rocprofv3 --kernel-trace --stats -d $O/kt_rollout -o kt --output-format csv -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/kt_rollout_bench.json 2>/dev/null
 cp $O/kt_rollout/*kernel_stats.csv $O/train_rollout_kernel_stats.csv
-rocprofv3 --kernel-trace --stats -d $O/kt_train -o kt --output-format csv -- python train.py --task_name stairs --terrain_file level4 --num_envs 4096 --num_timesteps 1300000 --num_evals 3 --index 904 > $O/train_run.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt_train -o kt --output-format csv -- python train.py --task_name stairs --terrain_file level4 --num_envs 4096 --num_timesteps 6553600 --num_evals 5 --index 904 > $O/train_run.txt 2>&1
 cp $O/kt_train/*kernel_stats.csv $O/train_ppo_kernel_stats.csv; tail -5 $O/train_run.txt
 for f in $O/bench_*.json $O/driver_cmd_bench.json $O/kt_bench.json; do python -c "import sys,json; d=json.load(open('$f')); print('$f', d['value'], d['ms_per_step'], d['kernels_ms'], d.get('wall_over_kernels'))"; done
 grep "physics_kernel<0" $O/pmc_summary.txt | grep -E "FETCH|WRITE|WAVE_CYCLES|WAIT_ANY|ACTIVE_INST_VALU|INSTS_|SQ_WAVES"
