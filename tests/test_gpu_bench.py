@@ -1,0 +1,47 @@
+"""The driver's own command, `python bench.py --gpus 1 --steps 20 --warmup 5`, on the GPU box: ONE JSON line with the contract's fields, the metric of
+BASELINE.json on its configuration, `roofline` and `cpu_baseline`, and the side rows this repository adds (other single-GPU configs, the roll-out
+row, the correctly-rounded-division side build).  A guard for the measurement, not a benchmark: thresholds are far below the measured values."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_driver_command_line_contract():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PGTT_LIB")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-sample-steps", "25"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["unit"] == "env-steps/s" and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["env_steps_allreduced"] == d["env_steps_expected"] == 4096 * 20 and "error" not in d and d["cold"] is False
+    assert abs(d["value"] - d["env_steps_allreduced"] / (d["ms_per_step"] * 1e-3 * 20)) < 1e-6 * d["value"]
+    assert d["value"] > 15e6                                     # target of the north star: 1 M; measured 22 - 23 M
+    c = d["config"]
+    assert "level4" in c["workload"] and c["envs_per_gpu"] == 4096 and c["prime_steps"] >= 100 and c["untimed_steps_before_clock"] == c["prime_steps"] + 5
+    assert "domain_randomize" in c["terrain_variants"] and c["fp32_div_sqrt"].startswith("1ulp")
+    r = d["roofline"]
+    assert r["kernel"] == "physics_kernel" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.1 < r["frac"] < 1.0
+    assert r["traffic"] is None or 3e6 < r["traffic"] < 2e7
+    k = d["kernels_ms"]
+    assert k["launches"] >= 3 and 0.05 < k["physics_kernel"] < 0.3 and 0.005 < k["observe_kernel"] < 0.05
+    assert k["physics_kernel"] + k["observe_kernel"] < d["ms_per_step"] * 1.05          # the kernels fit inside the step they are part of
+    b = d["cpu_baseline"]
+    assert b["kind"] == "port" and b["cores"] >= 1 and b["value"] > 0 and abs(b["per_core"] - b["value"] / b["cores"]) < 1e-6 * b["value"] and "25 control steps" in b["sample"]
+    rows = {(r_["workload"], r_["envs"], r_.get("fp32_div_sqrt")): r_ for r_ in d["other_configs"]}
+    assert rows[("flat", 4096, None)]["value"] > 20e6 and rows[("wfc_dr", 8192, None)]["value"] > 20e6 and rows[("level4", 32768, None)]["value"] > 20e6
+    roll = rows[("rollout", 4096, None)]
+    assert "skipped" not in roll and roll["value"] > 12e6 and roll["launches_per_step"] == 4             # >= 15 M asked for, 18 - 19 M measured
+    prec = rows[("level4", 4096, "correctly rounded")]
+    assert "skipped" not in prec and 0.8 * d["value"] < prec["value"] < 1.05 * d["value"]
