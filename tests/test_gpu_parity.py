@@ -297,6 +297,12 @@ def test_level4_parity_full_size():
     assert st["active_contacts"] > 20000
 
 
+def test_flat_parity_full_size():
+    """BASELINE configs[1] at its size: 4096 envs on the plane, no DR, layout auto (hex), 8 control steps against the oracle"""
+    st = run_parity("flat_terrain", 4096, None, steps=8)
+    assert st["active_contacts"] > 20000
+
+
 def test_wfc_dr_parity_full_size():
     """BASELINE configs[3] at its size: 8192 envs (layout auto = oct), WFC-generated terrain, full randomize.py DR, AutoReset on, 6 control steps"""
     from phase_guided_terrain_traversal_amd.terrain_gen import create_random_matrix
