@@ -211,3 +211,40 @@ def test_fused_acting_step_is_faster_than_the_torch_ops():
             os.environ.pop("PGTT_PPO_ACT_FUSED", None)
     print("acting step, env-steps/s: torch ops %.2f M, fused %.2f M" % (rate["0"] / 1e6, rate["1"] / 1e6))
     assert rate["1"] > 1.5 * rate["0"] and rate["1"] > 12e6
+
+
+@pytest.mark.parametrize("od", [215, 100, 16])
+def test_policy_act_other_observation_widths(od):
+    """pgtt_policy_act through the bare C ABI with observation widths other than the two tasks' (171 / 162 -> 11 k-blocks): 215 takes the second tuned
+    instantiation (14 k-blocks), anything else the generic loop - head equal to the PyTorch-op MLP, ragged env count"""
+    import ctypes as C
+    from phase_guided_terrain_traversal_amd import acting, native
+    L = acting._lib()
+    n = 203
+    torch.manual_seed(od)
+    dims = (od, 512, 256, 128, 24)
+    lins = [torch.nn.Linear(dims[i], dims[i + 1]).cuda() for i in range(4)]
+    obs = torch.randn(n, od, device="cuda") * 2
+    mean, std = torch.randn(od, device="cuda") * 0.3, torch.rand(od, device="cuda") + 0.5
+    packed = [pack_linear(l.weight, l.bias) for l in lins]
+    act, head = torch.zeros(n, 12, device="cuda"), torch.zeros(n, 24, device="cuda")
+    a = acting.PgttPolicyActArgs()
+    a.obs, a.priv, a.mean, a.std = obs.data_ptr(), None, mean.data_ptr(), std.data_ptr()
+    for i, (w, b) in enumerate(packed):
+        assert w.numel() == L.pgtt_policy_packed_floats(dims[i], dims[i + 1])
+        a.w[i], a.b[i] = w.data_ptr(), b.data_ptr()
+    a.eps, a.act, a.head = None, act.data_ptr(), head.data_ptr()
+    a.store_obs = a.store_priv = a.store_u = a.store_logp = None
+    a.counters, a.seed, a.env_id_offset = None, 1, 0
+    a.num_envs, a.obs_dim, a.priv_dim, a.deterministic = n, od, 0, 1
+    native.check(L.pgtt_policy_act(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        x = (obs - mean) / std
+        for l in lins[:-1]:
+            x = torch.nn.functional.silu(l(x))
+        want = lins[-1](x)
+    assert float((head - want).abs().max()) < 2e-5 * (1 + float(want.abs().max()))
+    assert float((act - torch.tanh(want[:, :12])).abs().max()) < 2e-5
+    a.obs_dim = 300                                   # wider than the kernel's LDS rows: refused, not truncated
+    assert L.pgtt_policy_act(C.byref(a), None) != 0
