@@ -79,6 +79,7 @@ def parse_args(argv=None):
     ap.add_argument("--unsorted-variants", action="store_true", help="terrain workloads: randomize.domain_randomize(group_variants=False), i.e. the variants in per-env draw order")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other single-GPU configs after the headline window")
     ap.add_argument("--other-steps", type=int, default=20)
+    ap.add_argument("--prime-steps", type=int, default=PRIME_STEPS, help="untimed steps after the reset before the W warm-up steps and the clock (device ramp, see PRIME_STEPS)")
     return ap.parse_args(argv)
 
 
@@ -165,7 +166,7 @@ WORKLOAD_TEXT = {
 OTHER_CONFIGS = [("flat", 4096, "BASELINE configs[1]"), ("wfc_dr", 8192, "BASELINE configs[3]"), ("level4", 32768, "single-GPU saturation of configs[2]")]
 
 
-def timed_window(env, n, steps, warmup, dev, rank, world, stub, sync):
+def timed_window(env, n, steps, warmup, dev, rank, world, stub, sync, prime_steps=PRIME_STEPS):
     """prime every code path, W untimed warm-up steps, then EXACTLY `steps` steps between barrier + synchronize on both sides.
     -> dict(dt = max-over-ranks wall seconds, ranks, physics_ms, observe_ms, launches, gemv_ms, env_steps)"""
     import torch
@@ -215,7 +216,7 @@ def timed_window(env, n, steps, warmup, dev, rank, world, stub, sync):
     # roll-out - busy.  A gap of host-bound work here (event read-back, the eight timed reductions above) used to let it clock down just
     # before the clock started: a 20-step window then read physics_kernel at 180 us against 168 us in the 300-step window.
     env.enable_timing(8)          # every 8th step: an event record costs a few us of GPU idle
-    run(0, (100 if stub else PRIME_STEPS) + warmup)
+    run(0, (100 if stub else prime_steps) + warmup)
     sums.zero_(); reducer.reduce(); env_steps_seen.zero_()               # counters back to zero (enqueued behind the warm-up steps)
     # timing counters back to zero: means are over the timed steps only - steps 4, 12, 20, ... of a long window, three steps of a short one
     # (a timed step is ~10 us longer: three event records)
@@ -292,7 +293,7 @@ def other_configs(args, local, dev, sync):
         a2 = copy.copy(args); a2.workload, a2.envs = workload, n
         t0 = time.perf_counter()
         env, cfg, terrain, task, dr = build_env(a2, 0, 1, local)
-        w = timed_window(env, n, args.other_steps, 5, dev, 0, 1, False, sync)
+        w = timed_window(env, n, args.other_steps, 5, dev, 0, 1, False, sync, args.prime_steps)
         env.close()
         ms = 1e3 * w["dt"] / args.other_steps
         r = rooflines(w, workload, n, dr, ms)
@@ -344,7 +345,7 @@ def rollout_row(args, local, dev, sync):
                 g.replay()
                 if (i + 1) % T == 0:
                     fa.rewind()                     # the learner would consume the [T, N] batch here
-        run(PRIME_STEPS // T * T)
+        run(max(args.prime_steps, T) // T * T)
         fa.episode_sums.zero_()
         sync()
         t1 = time.perf_counter()
@@ -371,7 +372,7 @@ def precise_build_row(args):
     if not os.path.exists(lib):
         return dict(row, skipped="libpgtt_precise.so not built (__graft_entry__.build() makes it)")
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.other_steps), "--warmup", "5", "--envs", str(args.envs), "--workload", args.workload,
-           "--layout", args.layout, "--no-cpu-baseline", "--no-other-configs"] + (["--unsorted-variants"] if args.unsorted_variants else [])
+           "--layout", args.layout, "--prime-steps", str(args.prime_steps), "--no-cpu-baseline", "--no-other-configs"] + (["--unsorted-variants"] if args.unsorted_variants else [])
     try:
         t0 = time.perf_counter()
         r = subprocess.run(cmd, env=dict(os.environ, PGTT_LIB=lib), capture_output=True, text=True, timeout=600)
@@ -405,7 +406,7 @@ def worker(args):
         env, cfg, terrain, task, dr = build_env(args, rank, world, local)
         sync = torch.cuda.synchronize
     n = args.envs
-    w = timed_window(env, n, args.steps, args.warmup, dev, rank, world, stub, sync)
+    w = timed_window(env, n, args.steps, args.warmup, dev, rank, world, stub, sync, args.prime_steps)
     dt, ranks, env_steps = w["dt"], w["ranks"], w["env_steps"]
     env.close()
 
@@ -422,7 +423,7 @@ def worker(args):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD_TEXT[args.workload],
                        "envs_per_gpu": n, "substeps": 4, "autoreset": True, "actions": "tanh(N(0,0.6)) iid", "parallelism": f"env-shard x{world}",
-                       "lane_layout": args.layout, "prime_steps": PRIME_STEPS, "untimed_steps_before_clock": PRIME_STEPS + args.warmup,
+                       "lane_layout": args.layout, "prime_steps": args.prime_steps, "untimed_steps_before_clock": args.prime_steps + args.warmup,
                        "terrain_variants": ("per-env draws in draw order (--unsorted-variants)" if args.unsorted_variants else
                                             "randomize.domain_randomize default: per-env draws, ascending within blocks of 4096 global env ids"),
                        "fp32_div_sqrt": FP32_DIV_SQRT,

@@ -123,13 +123,13 @@ void launch_physics(pgtt_env* h, const pgtt::KArgs& a_in, const float* action, h
        {{pgtt_launch_physics_s2_1_0_0, pgtt_launch_physics_s2_1_0_1}, {pgtt_launch_physics_s2_1_1_0, pgtt_launch_physics_s2_1_1_1}}}};
   // auto: a launch lasts as long as one wave's instruction stream while all its waves run concurrently, one per SIMD (<= 1024
   // waves), and the stream is the shorter the more lanes share an env: hex (4 envs per wave: line-search rows, Cholesky columns
-  // and - on box terrain - the collision passes and contact slots split over four sub-lanes) up to 4096 envs (level4 0.18 ms
-  // against 0.39 ms in the quad layout, flat ground 0.137 against 0.141 ms); beyond that oct (8 envs per wave, 34 KB of LDS per
-  // block = four blocks per CU): one round of waves up to 8192 envs, and still ahead of quad (16 envs per wave, 68 KB of LDS =
-  // two blocks per CU) at 16384 and 32768 envs (level4: 27.4 against 23.3 and 29.0 against 25.3 M env-steps/s).  The quad
-  // layout stays available through PgttConfig.lane_layout, and is the one for more than 8192 envs on FLAT ground: its flat kernels
-  // use no LDS, 16384 envs are one round of 1024 waves (0.135 ms = 80 M env-steps/s against 51 M in the oct layout's two rounds).
-  const int subs = h->layout != 0 ? h->layout : (h->N <= 4096 ? 4 : ((terr || h->N <= 8192) ? 2 : 1));
+  // and - on box terrain - the collision passes and contact slots split over four sub-lanes) up to 4096 envs (level4 0.16 ms
+  // against 0.31 ms in the quad layout); oct (8 envs per wave) up to 8192 envs = still one round of waves (0.26 ms against 0.31 ms
+  // for quad's 512 waves); beyond that QUAD (16 envs per wave): 16384 envs are ONE round of 1024 waves (0.34 ms) where oct needs
+  // two (0.47 ms).  On box terrain that holds since round 4: the quad kernels used to stage the env's box centres / extents in LDS
+  // (68 KB per workgroup = two per CU, i.e. two rounds at 16384 envs); they now read them from the L2-resident table (30 KB of
+  // LDS = one workgroup per SIMD): level4 at 16384 / 32768 envs 41.8 / 47.6 M env-steps/s against 31.7 / 33.9 M in the oct layout.
+  const int subs = h->layout != 0 ? h->layout : (h->N <= 4096 ? 4 : (h->N <= 8192 ? 2 : 1));
   const int per = 16 / subs;
   table[subs == 1 ? 0 : (subs == 4 ? 1 : 2)][MODE][dr ? 1 : 0][terr ? 1 : 0]((h->N + per - 1) / per, st, a, action);
 }

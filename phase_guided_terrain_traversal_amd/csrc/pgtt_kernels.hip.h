@@ -151,8 +151,8 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   int nbox = 0;
   // LDS staging of the env's terrain variant: centre + bounding radius of its <=100 boxes (read 2 x 4 substeps
   // by the broad phase), and a per-lane column for the broad-phase keys of the own foot
-  __shared__ float4 sh_box[HAS_TERRAIN ? PGTT_MAX_BOX * kEnvsPerWave : 1];      // (cx, cy, cz, hx)
-  __shared__ float2 sh_box2[HAS_TERRAIN ? PGTT_MAX_BOX * kEnvsPerWave : 1];     // (hy, hz)
+  __shared__ float4 sh_box[HAS_TERRAIN && kBoxLds ? PGTT_MAX_BOX * kEnvsPerWave : 1];      // (cx, cy, cz, hx)
+  __shared__ float2 sh_box2[HAS_TERRAIN && kBoxLds ? PGTT_MAX_BOX * kEnvsPerWave : 1];     // (hy, hz)
   __shared__ float sh_con[HAS_TERRAIN ? kMaxB * kSlotFields * kSlotCols : 1];
   const int quad = lane_env();                         // env within the wave
   const BoxSlots slots{sh_con, lane_col()};
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
     grid_v = a.grid + (long)variant * (kGridG * kGridG);
 #endif
     nbox = a.B;
-    for (int b = lane_in_env(); b < nbox; b += 4 * kSubs) {
+    for (int b = lane_in_env(); kBoxLds && b < nbox; b += 4 * kSubs) {
       const TerrainBox* tb = PG_ADDR32 ? &pg_at(boxes, box0 + (unsigned)b) : boxes + b;
       sh_box[b * kEnvsPerWave + quad] = make_float4(tb->px, tb->py, tb->pz, tb->hx);
       sh_box2[b * kEnvsPerWave + quad] = make_float2(tb->hy, tb->hz);

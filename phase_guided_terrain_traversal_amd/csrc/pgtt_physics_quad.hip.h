@@ -40,6 +40,9 @@ constexpr bool kTerrainTU = PG_TERRAIN != 0;
 constexpr bool kTerrainTU = false;
 #endif
 constexpr int kEnvsPerWave = 16 / PG_SUBS;
+// centre / world-AABB half extents of the env's boxes staged in LDS per env (hex, oct) or read from the resident table where they are needed (quad:
+// 16 envs x 100 boxes x 24 B = 38 KB per workgroup were what kept a CU at two quad workgroups; without them four fit, one per SIMD - collide())
+constexpr bool kBoxLds = PG_SUBS != 1;
 static_assert(PG_SUBS == 1 || PG_SUBS == 2 || PG_SUBS == 4, "lane layouts: quad, oct, hex");
 // who am I: sub-lane of the leg, leg of the env, env of the wave, lane of the env, LDS column of the (env, leg) pair
 PG_INL int lane_sub() { return kSubs == 4 ? (int)(threadIdx.x & 3) : (kSubs == 2 ? (int)(threadIdx.x & 1) : 0); }
@@ -723,6 +726,18 @@ struct QPhysics {
   PG_INL void collide(const TerrainBox* __restrict__ boxes, unsigned box0, int nbox, const float4* sh_box, const float2* sh_box2, const BoxSlots& slots, int quad,
                       const uint4* __restrict__ grid, unsigned cell0, float grid_E, float grid_inv) {
     auto box_rec = [&](int b) -> TerrainBox { if (PG_ADDR32) return pg_at(boxes, box0 + (unsigned)b); return boxes[b]; };
+    // (centre, hx) and (hy, hz) of box b: the LDS copy of the launch prologue, or - quad layout - the record itself (L2-resident: every lane of the
+    // wave reads the same few tables; the 100-box loops run about once per launch since the broad-phase proof is carried over the substeps)
+    auto boxA = [&](int b) -> float4 {
+      if (kBoxLds) return sh_box[b * kEnvsPerWave + quad];
+      const TerrainBox& t = pg_at(boxes, box0 + (unsigned)b);
+      return make_float4(t.px, t.py, t.pz, t.hx);
+    };
+    auto boxH = [&](int b) -> float2 {
+      if (kBoxLds) return sh_box2[b * kEnvsPerWave + quad];
+      const TerrainBox& t = pg_at(boxes, box0 + (unsigned)b);
+      return make_float2(t.hy, t.hz);
+    };
     const float rad = m->foot_radius[l];
     s.nbox = 0;
     if (boxes == nullptr || nbox <= 0) return;
@@ -766,8 +781,8 @@ struct QPhysics {
         cd[0] &= w == 0 ? ~one : ~0u; cd[1] &= w == 1 ? ~one : ~0u; cd[2] &= w == 2 ? ~one : ~0u; cd[3] &= w == 3 ? ~one : ~0u;
         const int bx = w * 32 + bit;
         const int b = bx < nbox ? bx : 0;
-        const float4 A = sh_box[b * kEnvsPerWave + quad];
-        const float2 H2 = sh_box2[b * kEnvsPerWave + quad];
+        const float4 A = boxA(b);
+        const float2 H2 = boxH(b);
         const float ex = fabsf(A.x - fx) - A.w, ey = fabsf(A.y - fy) - H2.x, ez = fabsf(A.z - fz) - H2.y;
         const float t = fmaxf(fmaxf(ex, ey), ez) - pad;
         const unsigned hit = ((__float_as_uint(t) >> 31) != 0u && bx < nbox) ? one : 0u;
@@ -872,7 +887,7 @@ struct QPhysics {
         for (;;) {
           if (__ballot((cm[0] | cm[1] | cm[2] | cm[3]) != 0u) == 0ull) break;
           const int b = pop();
-          const float4 A = sh_box[(b >= 0 ? b : 0) * kEnvsPerWave + quad];
+          const float4 A = boxA(b >= 0 ? b : 0);
           kmax = b >= 0 ? fmaxf(kmax, norm(v3(A.x, A.y, A.z) - s.footc) - keyC) : kmax;
         }
         cm[0] = sv0; cm[1] = sv1; cm[2] = sv2; cm[3] = sv3;
@@ -881,7 +896,7 @@ struct QPhysics {
         int cnt = 0;
 #pragma unroll 1
         for (int b = 0; b < nbox; b++) {
-          const float4 A = sh_box[b * kEnvsPerWave + quad];
+          const float4 A = boxA(b);
           const V3 dv = v3(A.x, A.y, A.z) - s.footc;
           cnt += dot(dv, dv) <= thr2 ? 1 : 0;
         }
@@ -910,7 +925,7 @@ struct QPhysics {
           int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
 #pragma unroll 1
           for (int bb = 0; bb < nbox; bb++) {
-            const float4 A = sh_box[bb * kEnvsPerWave + quad];
+            const float4 A = boxA(bb);
             const unsigned long long q = packed_key(norm(v3(A.x, A.y, A.z) - s.footc) - keyC, l * nbox + bb);
             r0 += q < c0 ? 1 : 0; r1 += q < c1 ? 1 : 0; r2 += q < c2 ? 1 : 0; r3 += q < c3 ? 1 : 0;
           }
@@ -994,7 +1009,7 @@ struct QPhysics {
       static_assert(PGTT_MAX_BOX <= 128, "hex layout: the <= 32 boxes of a sub-lane are one mask word");
 #pragma unroll 4
       for (int t = 0, b = lane_sub(); b < nbox; t++, b += kSubs) {     // hex / oct: boxes go round the sub-lanes
-        const float4 A = sh_box[b * kEnvsPerWave + quad];
+        const float4 A = boxA(b);
         V3 dv = v3(A.x, A.y, A.z) - s.footc;
         const float d2 = dot(dv, dv);
         const bool in = d2 <= thr2;
@@ -1042,12 +1057,12 @@ struct QPhysics {
         }
       };
       if (kSubs == 1) {
-        float4 An = sh_box[quad];
+        float4 An = boxA(0);
 #pragma unroll 1
         for (int b = 0; b < nbox; b++) {
           const float4 A = An;
           const int bn = b + 1 < PGTT_MAX_BOX ? b + 1 : b;       // next row, read while this one is ranked (rows >= nbox: stale, unused)
-          An = sh_box[bn * kEnvsPerWave + quad];
+          An = boxA(bn);
           rank_against(packed(norm(v3(A.x, A.y, A.z) - s.footc) - keyC, l * nbox + b));
         }
       } else if (kSubs == 2) {
@@ -1056,7 +1071,7 @@ struct QPhysics {
         for (int b0 = 0; b0 < nbox; b0 += 2) {
           const int b = b0 + (int)(threadIdx.x & 1);
           const bool have = b < nbox;
-          const float4 A = sh_box[(have ? b : 0) * kEnvsPerWave + quad];
+          const float4 A = boxA(have ? b : 0);
           const unsigned long long pk = packed(norm(v3(A.x, A.y, A.z) - s.footc) - keyC, l * nbox + b);
           rank_against(have ? pk : ~0ull);
         }
@@ -1071,7 +1086,7 @@ struct QPhysics {
           const int t = have ? __ffs(mk) - 1 : 0;
           mk &= mk - 1u;                                            // 0 stays 0
           const int b = (int)(threadIdx.x & 3) + 4 * t;
-          const float4 A = sh_box[b * kEnvsPerWave + quad];
+          const float4 A = boxA(b);
           const unsigned long long pk = packed(norm(v3(A.x, A.y, A.z) - s.footc) - keyC, l * nbox + b);
           rank_against(have ? pk : ~0ull);                          // ~0 sorts after every candidate
         }

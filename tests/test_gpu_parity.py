@@ -297,6 +297,14 @@ def test_level4_parity_full_size():
     assert st["active_contacts"] > 20000
 
 
+def test_level4_parity_16384_envs_quad_by_auto():
+    """beyond 8192 envs the automatic layout is quad (16 envs per wave, one workgroup per SIMD since its box data are read from the resident table
+    instead of an LDS copy): 16384 envs on level4 = one round of 1024 waves, 3 control steps against the oracle, product variant labelling"""
+    terrain = np.load(os.path.join(ASSETS, "terrains", "level4.npy"))
+    st = run_parity("stairs", 16384, terrain, steps=3, product_variants=True, w_floor=0.6)
+    assert st["active_contacts"] > 20000
+
+
 def test_flat_parity_full_size():
     """BASELINE configs[1] at its size: 4096 envs on the plane, no DR, layout auto (hex), 8 control steps against the oracle"""
     st = run_parity("flat_terrain", 4096, None, steps=8)
