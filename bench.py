@@ -20,7 +20,7 @@ ms_per_step / (physics + observe + the interval reduction's share of a step); "c
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (physics_kernel) with ITS share of the algorithmic work
 (1.2 MFLOP, 0.8 KB per env-step), `roofline_observe` / `roofline_step` the scan kernel and the whole step; `cpu_baseline` is the
 build's own CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded sample.  With one GPU the line
-also carries `other_configs`: BASELINE configs[1] (flat, 4096), configs[3] (WFC + DR, 8192) and level4 at 32768 envs, 20 steps
+also carries `other_configs`: BASELINE configs[1] (flat, 4096), configs[3] (WFC + DR, 8192) and level4 at 32768 envs, 100 steps
 each after the headline window (never part of `value`; --no-other-configs skips them).
 
 `--backend gloo` is a TEST HOOK (tests/test_distributed.py): CPU tensors and a stub env, so that the rank / barrier /
@@ -78,7 +78,7 @@ def parse_args(argv=None):
     ap.add_argument("--layout", default="auto", choices=["auto", "quad", "oct", "hex"], help="lane layout of physics_kernel (PgttConfig.lane_layout)")
     ap.add_argument("--unsorted-variants", action="store_true", help="terrain workloads: randomize.domain_randomize(group_variants=False), i.e. the variants in per-env draw order")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other single-GPU configs after the headline window")
-    ap.add_argument("--other-steps", type=int, default=20)
+    ap.add_argument("--other-steps", type=int, default=100)
     ap.add_argument("--prime-steps", type=int, default=PRIME_STEPS, help="untimed steps after the reset before the W warm-up steps and the clock (device ramp, see PRIME_STEPS)")
     return ap.parse_args(argv)
 
