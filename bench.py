@@ -20,8 +20,13 @@ ms_per_step / (physics + observe + the interval reduction's share of a step); "c
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (physics_kernel) with ITS share of the algorithmic work
 (1.2 MFLOP, 0.8 KB per env-step), `roofline_observe` / `roofline_step` the scan kernel and the whole step; `cpu_baseline` is the
 build's own CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded sample.  With one GPU the line
-also carries `other_configs`: BASELINE configs[1] (flat, 4096), configs[3] (WFC + DR, 8192) and level4 at 32768 envs, 100 steps
-each after the headline window (never part of `value`; --no-other-configs skips them).
+also carries `other_configs`: BASELINE configs[1] (flat, 4096), configs[3] (WFC + DR, 8192), level4 at 32768 envs, the seven per-rank
+workloads of configs[4] (one curriculum level file each, 4096 envs), the step loop replayed as ONE HIP graph per 20 steps, the roll-out row
+and the 1-ulp-division side build, 100 steps each after the headline window (never part of `value`; --no-other-configs skips them).
+
+`roofline.traffic` / `valu_busy` / `mfma_ops` come from the rocprofv3 --pmc passes committed under profiles/ (hbm_traffic.json, which
+records the SHA-256 of the kernel sources it was measured on); when the sources of the library being timed differ they are null and
+the line says "profile_stale": true.
 
 `--backend gloo` is a TEST HOOK (tests/test_distributed.py): CPU tensors and a stub env, so that the rank / barrier /
 MAX-over-ranks / rank-0-print path of this file runs without a GPU; its line carries "stub": true and is not a result.
@@ -60,8 +65,6 @@ COLD_RATIO = 1.5
 # first block when the roll-out is repeated) - clocks ramping, not the simulation.  BASELINE.md quotes the metric on the steady state, and
 # the driver's command times 20 steps: 1500 steps (0.3 s at 4096 envs) put that window where the 300-step default already is.
 PRIME_STEPS = 1500
-# how libpgtt.so was built (csrc/Makefile): fp32 `/` and sqrtf() as v_rcp / v_rsq + one refinement (1 ulp) unless PRECISE_DIV=1 (XLA: correctly rounded)
-FP32_DIV_SQRT = "1ulp (-fno-hip-fp32-correctly-rounded-divide-sqrt; `make PRECISE_DIV=1` builds the correctly rounded library, see other_configs)"
 
 
 def parse_args(argv=None):
@@ -193,6 +196,7 @@ def timed_window(env, n, steps, warmup, dev, rank, world, stub, sync, prime_step
 
     # ---- prime 1: every code path of the timed loop, whatever --warmup is (the driver runs --steps 20 --warmup 5)
     env.enable_timing(1)                                   # events recorded around the kernels of EVERY step
+    untimed = max(len(pool), 2 * REDUCE_EVERY) + (100 if stub else prime_steps) + warmup     # every step taken before the clock starts
     run(0, max(len(pool), 2 * REDUCE_EVERY))               # full pass over the pool, >= 2 all-reduces
     sync()
     env.kernel_ms_mean()                                   # the read-back path of the event ring
@@ -227,32 +231,46 @@ def timed_window(env, n, steps, warmup, dev, rank, world, stub, sync, prime_step
     t0 = time.perf_counter()
     run(0, steps)
     sync()
+    dt_own = time.perf_counter() - t0          # this rank's own K steps done (before it waits for the others)
     if world > 1:
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
-    ranks = 1
+    ranks, ranks_dt = 1, [dt_own]
     if steps % REDUCE_EVERY:
         flush(steps % REDUCE_EVERY)                    # the tail of the last interval (outside the clock)
     if world > 1:
         t = torch.tensor([dt, 1.0], device=dev, dtype=torch.float64)
         tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         ts = t.clone(); dist.all_reduce(ts, op=dist.ReduceOp.SUM)
-        dt, ranks = float(tm[0].item()), int(round(float(ts[1].item())))
+        # every rank's OWN time for its K steps, in rank order, taken before the closing barrier (the clock `dt` is taken after it and is the MAX
+        # over ranks): a slow GCD or a straggling process shows as one long entry
+        each = torch.zeros(world, device=dev, dtype=torch.float64); each[rank] = dt_own
+        dist.all_reduce(each, op=dist.ReduceOp.SUM)
+        dt, ranks, ranks_dt = float(tm[0].item()), int(round(float(ts[1].item()))), [float(x) for x in each.tolist()]
     phys_ms, obs_ms, ntimed = env.kernel_ms_mean()
     env.enable_timing(False)
-    return {"dt": dt, "ranks": ranks, "physics_ms": phys_ms, "observe_ms": obs_ms, "launches": ntimed, "gemv_ms": gemv_ms,
+    return {"dt": dt, "ranks": ranks, "ranks_dt": ranks_dt, "untimed_steps": untimed, "physics_ms": phys_ms, "observe_ms": obs_ms, "launches": ntimed, "gemv_ms": gemv_ms,
             "env_steps": float(env_steps_seen.item()), "done_frac": float(env.buffers["done"].mean().item())}
 
 
 def profile_record(workload, n):
     """counter figures measured with rocprofv3 --pmc on the same command and committed under profiles/ (hbm_traffic.json,
-    tools/collect_profiles.py): HBM bytes per physics_kernel launch, VALU-busy share of the wave cycles.  None when not measured."""
+    tools/collect_profiles.py): HBM bytes per physics_kernel launch, VALU-busy share of the wave cycles.  -> (record, stale): the file
+    carries the SHA-256 of the kernel sources its counters were measured on (native.source_sha256); when the library being timed was
+    built from other sources the record is withheld ({}, True).  ({}, False) when nothing was measured for this workload."""
+    from phase_guided_terrain_traversal_amd import native
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
-        return json.load(open(tpath)).get(f"{workload}_{n}", {})
+        allrec = json.load(open(tpath))
     except Exception:
-        return {}
+        return {}, False
+    rec = allrec.get(f"{workload}_{n}", {})
+    if not rec:
+        return {}, False
+    if allrec.get("_source", {}).get("csrc_sha256") != native.source_sha256():
+        return {}, True
+    return rec, False
 
 
 def rooflines(w, workload, n, dr, ms_per_step):
@@ -260,7 +278,7 @@ def rooflines(w, workload, n, dr, ms_per_step):
     (whole step over the wall time per step) and `roofline_hbm`.  Flops are the dense-MJX count of SURVEY 8d - the arithmetic of the
     reference, not what this formulation executes (arrowhead M / H: about a quarter) - so `valu_busy` from the counters is the
     better reading of how busy the machine is."""
-    rec = profile_record(workload, n)
+    rec, stale = profile_record(workload, n)
     traffic = rec.get("physics_bytes_per_launch")
     pf, of = ALGO_FLOP_PHYSICS * n, ALGO_FLOP_OBSERVE * n
     pb = (ALGO_BYTES_PHYSICS_DR if dr else ALGO_BYTES_PHYSICS) * n
@@ -273,6 +291,7 @@ def rooflines(w, workload, n, dr, ms_per_step):
         "roofline": line("valu_fp32", pf, w["physics_ms"], PEAK_FP32_TFLOPS, "TFLOP/s", 1e12, traffic=traffic, kernel="physics_kernel",
                          algorithmic_flop_per_env_step=ALGO_FLOP_PHYSICS, algorithmic_bytes_per_launch=pb,
                          traffic_over_algorithmic=(traffic / pb if traffic else None), valu_busy=rec.get("valu_busy"), mfma_ops=rec.get("mfma_ops"),
+                         profile_stale=stale,
                          note="FP32 vector-ALU issue / latency bound (SURVEY 8d): physics share of the dense-MJX count, 4 x 0.30 MFLOP per env-step; "
                               "MFMA deliberately unused (DESIGN 5.1); valu_busy = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES from profiles/"),
         "roofline_observe": line("valu_fp32", of, w["observe_ms"], PEAK_FP32_TFLOPS, "TFLOP/s", 1e12, kernel="observe_kernel",
@@ -302,9 +321,73 @@ def other_configs(args, local, dev, sync):
                      "wall_over_kernels": ms / (w["physics_ms"] + w["observe_ms"] + w["gemv_ms"]),
                      "roofline_frac_physics": r["roofline"]["frac"], "traffic": r["roofline"]["traffic"], "lane_layout": args.layout,
                      "setup_s": time.perf_counter() - t0 - w["dt"]})
+    # BASELINE configs[4], one rank's share at a time: 4096 envs on each level file of the reference's curriculum (training/training.sh:31-58)
+    for stage, lvl in enumerate(CURRICULUM):
+        a2 = copy.copy(args); a2.workload, a2.envs, a2.stage = "curriculum", 4096, stage
+        t0 = time.perf_counter()
+        env, cfg, terrain, task, dr = build_env(a2, 0, 1, local)
+        w = timed_window(env, 4096, args.other_steps, 5, dev, 0, 1, False, sync, min(args.prime_steps, 300))
+        env.close()
+        ms = 1e3 * w["dt"] / args.other_steps
+        rows.append({"workload": "curriculum", "envs": 4096, "stage": stage, "level": f"level{lvl}", "what": "BASELINE configs[4], one rank's workload",
+                     "value": w["env_steps"] / w["dt"], "unit": "env-steps/s", "steps": args.other_steps, "ms_per_step": ms,
+                     "kernels_ms": {"physics_kernel": w["physics_ms"], "observe_kernel": w["observe_ms"]}, "terrain_variants": int(terrain.shape[0]),
+                     "lane_layout": args.layout, "setup_s": time.perf_counter() - t0 - w["dt"]})
+    rows.append(graph_row(args, local, dev, sync))
     rows.append(rollout_row(args, local, dev, sync))
-    rows.append(precise_build_row(args))
+    rows.append(fastdiv_build_row(args))
     return rows
+
+
+def graph_row(args, local, dev, sync):
+    """the headline step loop as the reference runs its own: ONE device program per unroll (training/train.py:142 jits 20 env steps into a single
+    XLA executable).  Here: REDUCE_EVERY = 20 control steps (20 different action batches of the pool) + the interval reduction captured once
+    into a HIP graph, the timed window = replays of it.  No per-step launch gap, no event records: what is left is the kernels.  Never part of `value`."""
+    import copy
+    import torch
+    a2 = copy.copy(args); a2.workload, a2.envs = "level4", 4096
+    n, T = a2.envs, REDUCE_EVERY
+    replays = max(1, max(200, args.other_steps) // T)
+    row = {"workload": "graph", "envs": n, "what": f"headline workload, {T} control steps + interval reduction captured as ONE HIP graph, {replays} replays",
+           "steps": replays * T, "steps_per_graph": T, "lane_layout": args.layout}
+    try:
+        t0 = time.perf_counter()
+        env, cfg, terrain, task, dr = build_env(a2, 0, 1, local)
+        env.reset(seed=0)
+        g = torch.Generator(device=dev); g.manual_seed(1)
+        pool = [torch.tanh(torch.randn(n, 12, generator=g, device=dev) * 0.6) for _ in range(T)]
+        out = torch.zeros(env.buffers["interval_sums"].shape[0] + 1, dtype=torch.float32, device=dev)
+        total = torch.zeros_like(out)
+
+        def unroll():
+            for k in range(T):
+                env.step(pool[k])
+            env.interval_reduce(out, float(T) * n)
+            total.add_(out)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            unroll()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            unroll()
+        for _ in range(max(1, min(args.prime_steps, 1500) // T)):
+            graph.replay()
+        total.zero_()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(replays):
+            graph.replay()
+        sync()
+        dt = time.perf_counter() - t1
+        counted = float(total[-1].item())
+        row.update(value=counted / dt, unit="env-steps/s", ms_per_step=1e3 * dt / (replays * T), env_steps_counted=counted,
+                   env_steps_expected=float(n) * replays * T, setup_s=time.perf_counter() - t0 - dt)
+        env.close()
+    except Exception as e:          # a side row must never cost the headline line
+        row["skipped"] = f"{type(e).__name__}: {e}"
+    return row
 
 
 def rollout_row(args, local, dev, sync):
@@ -362,15 +445,15 @@ def rollout_row(args, local, dev, sync):
     return row
 
 
-def precise_build_row(args):
-    """the headline workload once more on libpgtt_precise.so (csrc/Makefile `make precise`: correctly rounded fp32 division / square root, what
-    XLA emits for the reference) in a process of its own (PGTT_LIB is read when the package loads its library): what the 1-ulp forms of the
-    product build are worth stays visible in the driver's line.  Never part of `value`."""
-    lib = os.path.join(ROOT, "phase_guided_terrain_traversal_amd", "libpgtt_precise.so")
-    row = {"workload": args.workload, "envs": args.envs, "what": "headline workload on the PRECISE_DIV=1 side build", "fp32_div_sqrt": "correctly rounded",
-           "steps": args.other_steps, "lane_layout": args.layout}
+def fastdiv_build_row(args):
+    """the headline workload once more on libpgtt_fastdiv.so (csrc/Makefile `make fastdiv`: fp32 division / square root as v_rcp / v_sqrt + one
+    refinement, 1 ulp - the product rounds them correctly, as XLA does for the reference) in a process of its own (PGTT_LIB is read when the
+    package loads its library): what correct rounding costs stays visible in the driver's line.  Never part of `value`."""
+    lib = os.path.join(ROOT, "phase_guided_terrain_traversal_amd", "libpgtt_fastdiv.so")
+    row = {"workload": args.workload, "envs": args.envs, "what": "headline workload on the 1-ulp division / square-root side build (libpgtt_fastdiv.so; NOT the product)",
+           "fp32_div_sqrt": "1ulp", "steps": args.other_steps, "lane_layout": args.layout}
     if not os.path.exists(lib):
-        return dict(row, skipped="libpgtt_precise.so not built (__graft_entry__.build() makes it)")
+        return dict(row, skipped="libpgtt_fastdiv.so not built (__graft_entry__.build() makes it)")
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.other_steps), "--warmup", "5", "--envs", str(args.envs), "--workload", args.workload,
            "--layout", args.layout, "--prime-steps", str(args.prime_steps), "--no-cpu-baseline", "--no-other-configs"] + (["--unsorted-variants"] if args.unsorted_variants else [])
     try:
@@ -418,19 +501,18 @@ def worker(args):
         ratio = ms_per_step / kern
         out = {
             "metric": "env-steps/sec at 4096 envs (Go2, level4 hfield), 1/2/4/8 MI355X",
-            "value": value, "unit": "env-steps/s", "n_gpus": ranks, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "env-steps/s", "n_gpus": ranks, "steps": args.steps, "warmup": w["untimed_steps"],
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD_TEXT[args.workload],
                        "envs_per_gpu": n, "substeps": 4, "autoreset": True, "actions": "tanh(N(0,0.6)) iid", "parallelism": f"env-shard x{world}",
-                       "lane_layout": args.layout, "prime_steps": args.prime_steps, "untimed_steps_before_clock": args.prime_steps + args.warmup,
+                       "lane_layout": args.layout, "warmup_arg": args.warmup, "prime_steps": args.prime_steps, "untimed_steps_before_clock": w["untimed_steps"],
                        "terrain_variants": ("per-env draws in draw order (--unsorted-variants)" if args.unsorted_variants else
                                             "randomize.domain_randomize default: per-env draws, ascending within blocks of 4096 global env ids"),
-                       "fp32_div_sqrt": FP32_DIV_SQRT,
                        "collective": f"fused {MetricReducer.SIZE}-float all-reduce every {REDUCE_EVERY} steps ({args.backend})"},
             "env_steps_allreduced": env_steps, "env_steps_expected": float(n) * world * args.steps,
             "kernels_ms": {"physics_kernel": w["physics_ms"], "observe_kernel": w["observe_ms"], "interval_reduce_per_step": w["gemv_ms"], "launches": w["launches"]},
-            "wall_over_kernels": ratio, "cold": bool(ratio > COLD_RATIO),
+            "ranks_dt": w["ranks_dt"], "wall_over_kernels": ratio, "cold": bool(ratio > COLD_RATIO),
             "done_fraction_last_step": w["done_frac"],
         }
         if stub:

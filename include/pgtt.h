@@ -230,7 +230,8 @@ typedef struct PgttBuffers {
   float*   ep_metrics;   /* [PGTT_NMETRIC + 2][N] running episode sums: metrics, sum_reward, length */
   /* optional */
   const float*   params;        /* [PGTT_NPARAM][N] or NULL */
-  const int32_t* variant;       /* [N] terrain variant per env, or NULL (=0) */
+  const int32_t* variant;       /* [N] terrain variant per env in [0, T), or NULL (=0).  pgtt_reset refuses labels outside the range (PGTT_E_ARG);
+                                 * the step kernels clamp them, so a label edited afterwards can never index past the terrain tables */
   const float*   box_friction;  /* [PGTT_MAX_BOX][N] sliding friction per env per box, or NULL */
   int32_t* dbg_contact;  /* [N][PGTT_NCON][2] (foot 0..3 FL,FR,RL,RR ; geom: -1 plane, box idx, -2 none) or NULL */
   float*   dbg_dist;     /* [N][PGTT_NCON] or NULL */
@@ -260,7 +261,9 @@ int pgtt_bind(pgtt_handle h, const PgttBuffers* bufs);
 
 /* Joystick.reset for the envs whose mask byte is non-zero (mask NULL => all). `seed` keys the Philox
  * streams; draws are a function of (seed, global env id, counter) only, so results do not depend on
- * how envs are sharded over GPUs. `env_id_offset` is the global id of local env 0. */
+ * how envs are sharded over GPUs. `env_id_offset` is the global id of local env 0.
+ * With a terrain and per-env variant labels bound, the labels are range-checked first (one launch + a 4-byte read-back: the ONE place where the
+ * library waits for `stream`; skipped while the stream is being captured into a graph): PGTT_E_ARG, nothing written, when one is outside [0, T). */
 int pgtt_reset(pgtt_handle h, uint64_t seed, int64_t env_id_offset, const uint8_t* mask_dev_or_null, void* stream);
 
 /* Joystick.step for all envs. action is [N][12] row-major (FR,FL,RR,RL), device pointer. */

@@ -55,6 +55,7 @@ typedef struct PgttPolicyActArgs {
   int64_t env_id_offset;       /* global id of env 0 of this shard (draws are keyed by global ids, like the env's own) */
   int32_t num_envs, obs_dim, priv_dim;
   int32_t deterministic;       /* non-zero: u = loc (evaluation, deploy/policy_net.py:71-80) */
+  int32_t store_rows;          /* T of the store_* blocks: a call whose row counters[0] is outside [0, T) stores nothing (the action is still produced) */
 } PgttPolicyActArgs;
 int pgtt_policy_act(const PgttPolicyActArgs* args, void* stream);
 int pgtt_policy_packed_floats(int in_dim, int out_dim);
@@ -72,6 +73,7 @@ typedef struct PgttRolloutRecordArgs {
   float* episode_sums;         /* [PGTT_NMETRIC + 3] += over the envs whose episode ended: 22 metric sums, return, length, count */
   float reward_scaling;
   int32_t num_envs, episode_length;
+  int32_t store_rows;          /* T of the store_* blocks: a call whose row counters[0] is outside [0, T) stores no row (sums and counters still advance) */
 } PgttRolloutRecordArgs;
 int pgtt_rollout_record(const PgttRolloutRecordArgs* args, void* stream);
 int pgtt_sizeof_policy_act_args(void);

@@ -27,13 +27,13 @@ _f, _i32, _p = C.c_float, C.c_int32, C.c_void_p
 class PgttPolicyActArgs(C.Structure):
     _fields_ = [("obs", _p), ("priv", _p), ("mean", _p), ("std", _p), ("w", _p * 4), ("b", _p * 4), ("eps", _p), ("act", _p), ("head", _p),
                 ("store_obs", _p), ("store_priv", _p), ("store_u", _p), ("store_logp", _p), ("counters", _p), ("seed", C.c_uint64),
-                ("env_id_offset", C.c_int64), ("num_envs", _i32), ("obs_dim", _i32), ("priv_dim", _i32), ("deterministic", _i32)]
+                ("env_id_offset", C.c_int64), ("num_envs", _i32), ("obs_dim", _i32), ("priv_dim", _i32), ("deterministic", _i32), ("store_rows", _i32)]
 
 
 class PgttRolloutRecordArgs(C.Structure):
     _fields_ = [("reward", _p), ("done", _p), ("ep_steps", _p), ("up_z", _p), ("ep_metrics", _p), ("store_rew", _p), ("store_done", _p),
                 ("store_trunc", _p), ("counters", _p), ("episode_sums", _p), ("reward_scaling", _f),
-                ("num_envs", _i32), ("episode_length", _i32)]
+                ("num_envs", _i32), ("episode_length", _i32), ("store_rows", _i32)]
 
 
 HIDDEN = (512, 256, 128)      # the kernel's layer widths = the reference's policy_hidden_layer_sizes (training/train.py:158)
@@ -92,7 +92,7 @@ class FusedActor:
         S = self.storage
         a.store_obs, a.store_priv, a.store_u, a.store_logp = S["obs"].data_ptr(), S["priv"].data_ptr(), S["u"].data_ptr(), S["logp"].data_ptr()
         a.counters, a.seed, a.env_id_offset = self.counters.data_ptr(), int(seed) & 0xFFFFFFFFFFFFFFFF, int(env.env_id_offset)
-        a.num_envs, a.obs_dim, a.priv_dim, a.deterministic = n, od, pd, 0
+        a.num_envs, a.obs_dim, a.priv_dim, a.deterministic, a.store_rows = n, od, pd, 0, self.T
         self._act_args = a
         r = PgttRolloutRecordArgs()
         r.reward, r.done = env.buffers["reward"].data_ptr(), env.buffers["done"].data_ptr()
@@ -101,7 +101,7 @@ class FusedActor:
         r.ep_metrics = env.buffers["ep_metrics"].data_ptr()
         r.store_rew, r.store_done, r.store_trunc = S["rew"].data_ptr(), S["done"].data_ptr(), S["trunc"].data_ptr()
         r.counters, r.episode_sums = self.counters.data_ptr(), self.episode_sums.data_ptr()
-        r.reward_scaling, r.num_envs, r.episode_length = float(reward_scaling), n, int(env.config["episode_length"])
+        r.reward_scaling, r.num_envs, r.episode_length, r.store_rows = float(reward_scaling), n, int(env.config["episode_length"]), self.T
         self._rec_args = r
 
     def _stream(self) -> int:

@@ -13,7 +13,8 @@
 
 // the physics_kernel instantiations (3 lane layouts x step/forward x DR x terrain) live in their own translation units
 // (pgtt_physics_inst.hip, compiled in parallel); this file only sees their host launchers
-#define PG_DECL(S, M, D, T) void pgtt_launch_physics_s##S##_##M##_##D##_##T(int nblocks, hipStream_t st, const pgtt::KArgs& a, const float* action);
+// weak: a side build may compile a subset of the variants (csrc/Makefile `fastdiv`); launching a missing one is a PGTT_E_STATE
+#define PG_DECL(S, M, D, T) __attribute__((weak)) void pgtt_launch_physics_s##S##_##M##_##D##_##T(int nblocks, hipStream_t st, const pgtt::KArgs& a, const float* action);
 #define PG_DECL8(S) PG_DECL(S, 0, 0, 0) PG_DECL(S, 0, 0, 1) PG_DECL(S, 0, 1, 0) PG_DECL(S, 0, 1, 1) PG_DECL(S, 1, 0, 0) PG_DECL(S, 1, 0, 1) PG_DECL(S, 1, 1, 0) PG_DECL(S, 1, 1, 1)
 PG_DECL8(1) PG_DECL8(2) PG_DECL8(4)
 #undef PG_DECL8
@@ -51,6 +52,7 @@ struct pgtt_env {
   long long env_off = 0;
   float test_rng_fix = NAN; int test_scan_preset = 0;   // pgtt_set_test_overrides
   float* d_handover = nullptr;    // [N][kHandover]: physics -> observe hand-over of one pgtt_step (pgtt_kernels.hip.h, KArgs)
+  int* d_flag = nullptr; int* h_flag = nullptr;      // pgtt_reset's range check of the caller's terrain-variant labels (device word, pinned host word)
   bool timing = false;
   int timing_period = 1, timing_tick = 0; bool timing_now = false;   // time every timing_period-th step (event records cost ~3 us of GPU idle each)
   bool split_observe = false;     // observe = observe_kernel<OBS_STEP_OBS> + task_kernel (PgttConfig.observe_form)
@@ -105,8 +107,16 @@ int harvest(pgtt_env* h, int r) {
   return PGTT_OK;
 }
 
+// number of labels outside [0, T): the step kernels clamp such a label (no out-of-bounds read), pgtt_reset reports it
+__global__ void variant_range_kernel(const int32_t* __restrict__ variant, int N, int T, int* __restrict__ bad) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool out = e < N && (variant[e] < 0 || variant[e] >= T);
+  const unsigned long long b = __ballot(out);
+  if (b != 0ull && (threadIdx.x & 63) == 0) atomicAdd(bad, __popcll(b));
+}
+
 template <int MODE>
-void launch_physics(pgtt_env* h, const pgtt::KArgs& a_in, const float* action, hipStream_t st) {
+int launch_physics(pgtt_env* h, const pgtt::KArgs& a_in, const float* action, hipStream_t st) {
   pgtt::KArgs a = a_in;
 #if defined(PGTT_TRACE) || defined(PGTT_TIME)
   a.trace = pgtt_trace_buffer() + 65536 * (g_trace_launch++ & 3);
@@ -131,7 +141,10 @@ void launch_physics(pgtt_env* h, const pgtt::KArgs& a_in, const float* action, h
   // LDS = one workgroup per SIMD): level4 at 16384 / 32768 envs 41.8 / 47.6 M env-steps/s against 31.7 / 33.9 M in the oct layout.
   const int subs = h->layout != 0 ? h->layout : (h->N <= 4096 ? 4 : (h->N <= 8192 ? 2 : 1));
   const int per = 16 / subs;
-  table[subs == 1 ? 0 : (subs == 4 ? 1 : 2)][MODE][dr ? 1 : 0][terr ? 1 : 0]((h->N + per - 1) / per, st, a, action);
+  const launcher fn = table[subs == 1 ? 0 : (subs == 4 ? 1 : 2)][MODE][dr ? 1 : 0][terr ? 1 : 0];
+  if (!fn) return fail(PGTT_E_STATE, "this build of the library does not contain the physics_kernel variant the call needs (lane layout / DR / terrain); use libpgtt.so");
+  if (a_in.N > 0) fn((h->N + per - 1) / per, st, a, action);      // N = 0 in the arguments: availability probe only (pgtt_reset, before it writes anything)
+  return PGTT_OK;
 }
 
 template <int OMODE>
@@ -152,7 +165,7 @@ int check_ready(pgtt_env* h) {
 extern "C" {
 
 const char* pgtt_last_error(void) { return g_err.c_str(); }
-const char* pgtt_version(void) { return "pgtt-mi355x 0.4 (gfx950)"; }
+const char* pgtt_version(void) { return "pgtt-mi355x 0.5 (gfx950)"; }
 int pgtt_obs_dims(const PgttConfig* cfg, int* state_dim, int* priv_dim) {
   if (!cfg || !state_dim || !priv_dim) return fail(PGTT_E_ARG, "pgtt_obs_dims: null argument");
   if (cfg->method != PGTT_METHOD_PGTT && cfg->method != PGTT_METHOD_BASELINE) return fail(PGTT_E_ARG, "pgtt_obs_dims: unknown method");
@@ -197,6 +210,8 @@ int pgtt_create(const PgttConfig* cfg, const PgttModel* model, int device, int n
     HIP_TRY(hipMalloc(&h->d_cfg, sizeof(PgttConfig)));
     HIP_TRY(hipMalloc(&h->d_model, sizeof(PgttModel)));
     HIP_TRY(hipMalloc(&h->d_handover, (size_t)num_envs * pgtt::kHandover * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_flag, sizeof(int)));
+    HIP_TRY(hipHostMalloc(&h->h_flag, sizeof(int)));
     HIP_TRY(hipMemcpy(h->d_cfg, cfg, sizeof(PgttConfig), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_model, model, sizeof(PgttModel), hipMemcpyHostToDevice));
     for (int r = 0; r < pgtt_env::kRing; r++) for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&h->ev[r][i]));
@@ -213,6 +228,8 @@ int pgtt_destroy(pgtt_handle h) {
   if (h->d_cfg) hipFree(h->d_cfg);
   if (h->d_model) hipFree(h->d_model);
   if (h->d_handover) hipFree(h->d_handover);
+  if (h->d_flag) hipFree(h->d_flag);
+  if (h->h_flag) hipHostFree(h->h_flag);
   if (h->d_terrain) hipFree(h->d_terrain);
   if (h->d_cull) hipFree(h->d_cull);
   if (h->d_grid) hipFree(h->d_grid);
@@ -225,6 +242,9 @@ int pgtt_set_terrain(pgtt_handle h, const float* boxes, int T, int B) {
   if (!h) return fail(PGTT_E_ARG, "null handle");
   if (T < 0 || B < 0 || B > PGTT_MAX_BOX) return fail(PGTT_E_ARG, "pgtt_set_terrain: need 0 <= B <= 100, T >= 0");
   if (T > 0 && (!boxes || B == 0)) return fail(PGTT_E_ARG, "pgtt_set_terrain: null table");
+  // the quad / oct step kernels address both tables through 32-bit BYTE offsets from their bases (PG_ADDR32, pgtt_physics.hip.h)
+  if ((unsigned long long)T * (unsigned long long)B * sizeof(pgtt::TerrainBox) >= (1ull << 32) || (unsigned long long)T * pgtt::kGridG * pgtt::kGridG * sizeof(uint4) >= (1ull << 32))
+    return fail(PGTT_E_ARG, "pgtt_set_terrain: terrain table too large (T * B * 80 bytes and T * 4096 bytes must stay below 4 GiB)");
   HIP_TRY(hipSetDevice(h->device));
   if (h->d_terrain) { HIP_TRY(hipFree(h->d_terrain)); h->d_terrain = nullptr; }
   if (h->d_cull) { HIP_TRY(hipFree(h->d_cull)); h->d_cull = nullptr; }
@@ -310,14 +330,30 @@ int pgtt_reset(pgtt_handle h, uint64_t seed, int64_t env_id_offset, const uint8_
   if (int rc = check_ready(h)) return rc;
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
+  dim3 grid((h->N + 63) / 64), block(64);
+  if (h->T > 0 && h->buf.variant) {
+    // every env's terrain-variant label must name one of the T variants of pgtt_set_terrain.  One launch + a 4-byte read-back BEFORE anything is
+    // written; this is the one place where the library waits for the stream (reset is off the steady-state path: AutoReset lives in the step).
+    // Not while the stream is being captured into a graph (a capture cannot wait) - the kernels clamp the label either way.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    HIP_TRY(hipStreamIsCapturing(st, &cap));
+    if (cap == hipStreamCaptureStatusNone) {
+      HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(int), st));
+      hipLaunchKernelGGL(variant_range_kernel, grid, block, 0, st, h->buf.variant, h->N, h->T, h->d_flag);
+      HIP_TRY(hipMemcpyAsync(h->h_flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (*h->h_flag != 0)
+        return fail(PGTT_E_ARG, "pgtt_reset: " + std::to_string(*h->h_flag) + " terrain variant label(s) outside [0, " + std::to_string(h->T) + ") in PgttBuffers.variant");
+    }
+  }
   h->seed = seed; h->env_off = env_id_offset;
   pgtt::KArgs a = make_args(h, mask, 0.f);
-  dim3 grid((h->N + 63) / 64), block(64);
+  { pgtt::KArgs probe = a; probe.N = 0; if (int rc = launch_physics<pgtt::MODE_FORWARD>(h, probe, nullptr, st)) return rc; }
   hipLaunchKernelGGL(pgtt::reset_pose_kernel<0>, grid, block, 0, st, a);
-  launch_physics<pgtt::MODE_FORWARD>(h, a, nullptr, st);          // mjx_env.init -> forward
+  if (int rc = launch_physics<pgtt::MODE_FORWARD>(h, a, nullptr, st)) return rc;          // mjx_env.init -> forward
   launch_observe<pgtt::OBS_SCAN_LIFT>(h, a, nullptr, st);         // lift by the max terrain height under the footprint
   a.write_qpos = 1;
-  launch_physics<pgtt::MODE_FORWARD>(h, a, nullptr, st);          // mjx.forward on the lifted pose
+  if (int rc = launch_physics<pgtt::MODE_FORWARD>(h, a, nullptr, st)) return rc;          // mjx.forward on the lifted pose
   launch_observe<pgtt::OBS_RESET>(h, a, nullptr, st);             // info, obs, first-state capture
   HIP_TRY(hipGetLastError());
   return PGTT_OK;
@@ -335,7 +371,7 @@ int pgtt_physics(pgtt_handle h, const float* action, void* stream) {
     if (int rc = harvest(h, h->ev_slot)) return rc;
     HIP_TRY(hipEventRecord(h->ev[h->ev_slot][0], st));
   }
-  launch_physics<pgtt::MODE_STEP>(h, a, action, st);
+  if (int rc = launch_physics<pgtt::MODE_STEP>(h, a, action, st)) return rc;
   if (h->timing_now) HIP_TRY(hipEventRecord(h->ev[h->ev_slot][1], st));
   HIP_TRY(hipGetLastError());
   return PGTT_OK;

@@ -113,7 +113,8 @@ __global__ __launch_bounds__(64) void physics_kernel(KArgs a, const float* __res
   // model through its global pointer (gm), everything after the barrier through `m`.
   __shared__ unsigned sh_model[kSubs == 4 ? (sizeof(PgttModel) + 3) / 4 : 1];
   const PgttModel* __restrict__ gm = a.model;
-  const int variant = (HAS_TERRAIN && a.buf.variant) ? a.buf.variant[e] : 0;
+  // a label outside [0, T) would index past the terrain tables: clamped (v_med3, identity for a valid label; pgtt_reset reports such labels as PGTT_E_ARG)
+  const int variant = (HAS_TERRAIN && a.buf.variant) ? min(max(a.buf.variant[e], 0), a.T - 1) : 0;
   constexpr int kModelWords = (int)((sizeof(PgttModel) + 3) / 4), kModelTrips = (kModelWords + 63) / 64;
   unsigned mw[kSubs == 4 ? kModelTrips : 1];
   if (kSubs == 4) {
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(64, 4) void observe_kernel(KArgs a, const float* __
   const TerrainBox* __restrict__ boxes = nullptr;
   float4 brec[2];
   if (HAS_TERRAIN) {
-    const int v = a.buf.variant ? a.buf.variant[e] : 0;
+    const int v = a.buf.variant ? min(max(a.buf.variant[e], 0), a.T - 1) : 0;      // clamped like in physics_kernel
     boxes = a.terrain + (long)v * a.B;
 #pragma unroll
     for (int h = 0; h < 2; h++) brec[h] = a.cull[(long)v * a.B + min(lane + 64 * h, a.B - 1)];

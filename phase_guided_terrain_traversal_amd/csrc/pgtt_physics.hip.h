@@ -48,8 +48,8 @@ struct TerrainBox {                 // resident terrain table entry (80 B), buil
 template <class T> PG_INL const T& pg_at(const T* base, unsigned idx) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)(idx * (unsigned)sizeof(T))); }
 template <class T> PG_INL T& pg_at(T* base, unsigned idx) { return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (size_t)(idx * (unsigned)sizeof(T))); }
 #if PG_ADDR32
-#define PG_ROW(base, row, N, e) pgtt::pg_at(base, (unsigned)((row) * (N) + (e)))
-#define PG_REC(base, e, stride, i) pgtt::pg_at(base, (unsigned)((e) * (stride) + (i)))
+#define PG_ROW(base, row, N, e) pgtt::pg_at(base, (unsigned)(row) * (unsigned)(N) + (unsigned)(e))
+#define PG_REC(base, e, stride, i) pgtt::pg_at(base, (unsigned)(e) * (unsigned)(stride) + (unsigned)(i))
 #else
 #define PG_ROW(base, row, N, e) ((base)[(row) * (long)(N) + (e)])
 #define PG_REC(base, e, stride, i) ((base)[(long)(e) * (stride) + (i)])

@@ -43,6 +43,7 @@ constexpr int kEnvsPerWave = 16 / PG_SUBS;
 // centre / world-AABB half extents of the env's boxes staged in LDS per env (hex, oct) or read from the resident table where they are needed (quad:
 // 16 envs x 100 boxes x 24 B = 38 KB per workgroup were what kept a CU at two quad workgroups; without them four fit, one per SIMD - collide())
 constexpr bool kBoxLds = PG_SUBS != 1;
+static_assert(kBoxLds || PG_ADDR32, "collide()'s boxA / boxH read the resident table through box0 (a 32-bit element index from the table's base)");
 static_assert(PG_SUBS == 1 || PG_SUBS == 2 || PG_SUBS == 4, "lane layouts: quad, oct, hex");
 // who am I: sub-lane of the leg, leg of the env, env of the wave, lane of the env, LDS column of the (env, leg) pair
 PG_INL int lane_sub() { return kSubs == 4 ? (int)(threadIdx.x & 3) : (kSubs == 2 ? (int)(threadIdx.x & 1) : 0); }
@@ -1061,7 +1062,7 @@ struct QPhysics {
 #pragma unroll 1
         for (int b = 0; b < nbox; b++) {
           const float4 A = An;
-          const int bn = b + 1 < PGTT_MAX_BOX ? b + 1 : b;       // next row, read while this one is ranked (rows >= nbox: stale, unused)
+          const int bn = b + 1 < nbox ? b + 1 : b;               // next row, read while this one is ranked (never a record past the variant's own: the table ends with the last variant's last box)
           An = boxA(bn);
           rank_against(packed(norm(v3(A.x, A.y, A.z) - s.footc) - keyC, l * nbox + b));
         }

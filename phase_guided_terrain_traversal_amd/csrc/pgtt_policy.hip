@@ -119,6 +119,7 @@ __global__ __launch_bounds__(kThreads) void policy_act_kernel(PgttPolicyActArgs 
   const int N = a.num_envs, od = a.obs_dim, kp0 = (od + 15) & ~15, ks0 = kp0 + 4, kb0n = kp0 >> 4;
   const long e0 = (long)blockIdx.x * kEnvs;
   const long t_row = a.counters ? a.counters[0] : 0;
+  const bool row_ok = t_row >= 0 && t_row < a.store_rows;      // a caller that ran past its storage (no rewind) gets actions, not an out-of-bounds store
   const float4* W0 = reinterpret_cast<const float4*>(a.w[0]);
   // ---- stage the 16 observations (contiguous rows), normalised; the storage copies ride along.  Every load of the prologue is issued before the
   //      first store (unrolled, bounds by predicates): as load -> store loops the seven trips of the copies were seven dependent HBM round trips
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(kThreads) void policy_act_kernel(PgttPolicyActArgs 
     constexpr int kPrivTrips = (kEnvs * kMaxObsPad + kThreads - 1) / kThreads;      // 7: priv_dim <= kMaxObsPad
     const int env = tid >> 5, k0 = tid & 31;
     const long e = e0 + env;
-    const bool copy_priv = a.store_priv && a.priv;
+    const bool copy_priv = a.store_priv && a.priv && row_ok;
     const int pd = a.priv_dim;
     const long pbase = e0 * pd, plim = (long)N * pd;
     float o[kObsTrips], mu[kObsTrips], sd[kObsTrips], pv[kPrivTrips];
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void policy_act_kernel(PgttPolicyActArgs 
     for (int j = 0; j < kObsTrips; j++) {
       const int k = k0 + 32 * j;
       if (k < kp0) bufB[env * ks0 + k] = (k < od && e < N) ? (o[j] - mu[j]) / sd[j] : 0.f;
-      if (a.store_obs && k < od && e < N) a.store_obs[(t_row * N + e) * od + k] = o[j];
+      if (a.store_obs && row_ok && k < od && e < N) a.store_obs[(t_row * N + e) * od + k] = o[j];
     }
 #pragma unroll
     for (int j = 0; j < kPrivTrips; j++) {
@@ -226,12 +227,12 @@ __global__ __launch_bounds__(kThreads) void policy_act_kernel(PgttPolicyActArgs 
     if (e < N) {
       const float th = tanhf(u);
       a.act[e * kA + j] = th;
-      if (a.store_u) a.store_u[(t_row * N + e) * kA + j] = u;
+      if (a.store_u && row_ok) a.store_u[(t_row * N + e) * kA + j] = u;
       if (a.head) { a.head[e * kOut + j] = loc; a.head[e * kOut + kA + j] = raw; }
     }
   }
   __syncthreads();
-  if (tid < kEnvs && e0 + tid < N && a.store_logp) {
+  if (tid < kEnvs && e0 + tid < N && a.store_logp && row_ok) {
     float lp = 0.f;
 #pragma unroll
     for (int j = 0; j < kA; j++) lp += sh_lp[tid * kA + j];
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(kRecThreads) void rollout_record_kernel(PgttRollout
   const int N = a.num_envs;
   const long t_row = a.counters[0];
   const long draws = a.counters[1];
+  const bool row_ok = t_row >= 0 && t_row < a.store_rows;
   float sums[kRecSums];
 #pragma unroll
   for (int k = 0; k < kRecSums; k++) sums[k] = 0.f;
@@ -260,9 +262,11 @@ __global__ __launch_bounds__(kRecThreads) void rollout_record_kernel(PgttRollout
     const float done = a.done[e], rew = a.reward[e];
     const bool fallen = a.up_z[e] < 0.f;
     const bool trunc = (a.ep_steps[e] >= a.episode_length) && !fallen;
-    a.store_rew[t_row * N + e] = rew * a.reward_scaling;
-    a.store_done[t_row * N + e] = done;
-    a.store_trunc[t_row * N + e] = trunc ? 1.f : 0.f;
+    if (row_ok) {
+      a.store_rew[t_row * N + e] = rew * a.reward_scaling;
+      a.store_done[t_row * N + e] = done;
+      a.store_trunc[t_row * N + e] = trunc ? 1.f : 0.f;
+    }
     if (done != 0.f) {
       any = true;
 #pragma unroll
@@ -296,13 +300,14 @@ extern "C" int pgtt_policy_act(const PgttPolicyActArgs* args, void* stream) {
   for (int l = 0; l < 4; l++) if (!args->w[l] || !args->b[l]) return PGTT_E_ARG;
   if (args->obs_dim <= 0 || ((args->obs_dim + 15) & ~15) > kMaxObsPad) return PGTT_E_ARG;
   if (args->store_priv && (!args->priv || args->priv_dim <= 0 || args->priv_dim > kMaxObsPad)) return PGTT_E_ARG;
+  if ((args->store_obs || args->store_priv || args->store_u || args->store_logp) && args->store_rows <= 0) return PGTT_E_ARG;
   hipLaunchKernelGGL(policy_act_kernel, dim3((args->num_envs + kEnvs - 1) / kEnvs), dim3(kThreads), 0, (hipStream_t)stream, *args);
   return hipGetLastError() == hipSuccess ? PGTT_OK : PGTT_E_HIP;
 }
 
 extern "C" int pgtt_rollout_record(const PgttRolloutRecordArgs* args, void* stream) {
   if (!args || !args->reward || !args->done || !args->ep_steps || !args->up_z || !args->ep_metrics || !args->store_rew || !args->store_done ||
-      !args->store_trunc || !args->counters || !args->episode_sums || args->num_envs <= 0) return PGTT_E_ARG;
+      !args->store_trunc || !args->counters || !args->episode_sums || args->num_envs <= 0 || args->store_rows <= 0) return PGTT_E_ARG;
   hipLaunchKernelGGL(rollout_record_kernel, dim3(1), dim3(kRecThreads), 0, (hipStream_t)stream, *args);
   return hipGetLastError() == hipSuccess ? PGTT_OK : PGTT_E_HIP;
 }

@@ -23,6 +23,29 @@ class PgttError(RuntimeError):
     pass
 
 
+def source_sha256() -> str:
+    """SHA-256 over the sources libpgtt.so is built from (csrc/*.hip, csrc/*.h, csrc/Makefile, include/*.h; names and contents, sorted):
+    tools/collect_profiles.py stores it next to the rocprofv3 counters it commits, bench.py compares it before quoting them."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) + [os.path.join(_HERE, "csrc", "Makefile")]
+                   + glob.glob(os.path.join(inc, "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def library_sha256(path: Optional[str] = None) -> str:
+    import hashlib
+    with open(path or LIB_PATH, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()
+
+
 def lib() -> C.CDLL:
     global _LIB
     if _LIB is None:

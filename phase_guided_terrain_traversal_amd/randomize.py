@@ -22,7 +22,11 @@ Terrain variants are drawn per env like the reference's ``rand_idx`` (randomize.
 order within every block of ``VARIANT_GROUP`` consecutive GLOBAL env ids (`group_variants`): the multiset of draws of a block is untouched
 (env ids are exchangeable labels and every other per-env draw is independent of the variant), but neighbouring envs now stand on the same
 variant, and since ``physics_kernel`` hands each XCD a contiguous range of envs, each XCD's L2 pulls ~1/8 of the terrain table per launch
-instead of all of it (profiles/hbm_traffic.json).  The order depends on global ids and the job's total only, so shards stay invariant.
+instead of all of it (profiles/hbm_traffic.json).  The order depends on global ids and the job's total only, so shards stay invariant -
+which is why a call for a shard (``env_id_offset != 0``) must pass ``total_envs``.  A consequence for data-parallel jobs with fewer than
+``VARIANT_GROUP`` envs per rank: a rank owns a contiguous SLICE of a sorted block, i.e. a contiguous range of variant ids (rank 0 the lowest),
+so per-rank metrics are skewed by variant difficulty; only the all-reduced means are comparable between job shapes.  With >= 4096 envs per
+rank (the reference's batch) every rank owns whole blocks and sees every variant.  ``group_variants=False`` gives the draw order.
 """
 from __future__ import annotations
 
@@ -57,8 +61,13 @@ def _variant_draws(seed: int, first_env: int, n: int, T: int) -> np.ndarray:
 def grouped_variants(seed: int, first_env: int, n: int, T: int, total_envs: Optional[int] = None) -> np.ndarray:
     """the draws of `_variant_draws`, ascending within each block of VARIANT_GROUP global env ids (the last block ends at `total_envs`, the
     job's env count - default: this shard is the job's last): a permutation of every block's own draws, a function of global ids alone"""
+    if total_envs is None and first_env != 0:
+        # a shard that is not the job's last one and does not end on a block boundary would sort a PARTIAL block and silently differ from the
+        # full batch: a call with an offset must say how many envs the job has
+        raise ValueError("grouped terrain variants of a shard (env_id_offset != 0) need total_envs = the env count of the whole job")
     total = first_env + n if total_envs is None else int(total_envs)
-    assert first_env + n <= total, "shard reaches beyond the job's env count"
+    if first_env + n > total:
+        raise ValueError("shard reaches beyond the job's env count (total_envs)")
     g0 = (first_env // VARIANT_GROUP) * VARIANT_GROUP
     g1 = min(-(-(first_env + n) // VARIANT_GROUP) * VARIANT_GROUP, total)
     v = _variant_draws(seed, g0, g1 - g0, T)

@@ -58,7 +58,7 @@ def test_dr_is_shard_invariant():
     m = mjcf.load_model("stairs")
     terr = np.load(os.path.join(os.path.dirname(mjcf.__file__), "assets", "terrains", "level4.npy"))
     full = domain_randomize(m, 24, seed=5, terrain=terr)
-    part = domain_randomize(m, 8, seed=5, terrain=terr, env_id_offset=16)
+    part = domain_randomize(m, 8, seed=5, terrain=terr, env_id_offset=16, total_envs=24)
     assert np.array_equal(full["params"][:, 16:24], part["params"])
     assert np.array_equal(full["variant"][16:24], part["variant"])
     assert np.array_equal(full["box_friction"][:, 16:24], part["box_friction"])
@@ -114,7 +114,11 @@ def test_bench_loop_world2_spawned_gloo():
                         "--warmup", "5", "--envs", "64"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     d = _bench_line(p.stdout)
-    assert d["stub"] is True and d["n_gpus"] == 2 and d["steps"] == 45 and d["warmup"] == 5
+    assert d["stub"] is True and d["n_gpus"] == 2 and d["steps"] == 45
+    # top-level "warmup" = EVERY untimed step before the clock (code-path priming 40 + prime 100 in the stub + the 5 asked for); the argument stays in config
+    assert d["warmup"] == d["config"]["untimed_steps_before_clock"] == 40 + 100 + 5 and d["config"]["warmup_arg"] == 5
+    # one entry per rank, each rank's own time for its K steps before the closing barrier; the clock is their maximum (+ the barrier)
+    assert len(d["ranks_dt"]) == 2 and all(0 < t <= d["ms_per_step"] * 1e-3 * 45 * 1.0001 for t in d["ranks_dt"])
     # the all-reduced env-step count proves both ranks contributed every interval, tail included (45 = 2 x 20 + 5)
     assert d["env_steps_allreduced"] == d["env_steps_expected"] == 2 * 64 * 45
     assert abs(d["value"] - d["env_steps_allreduced"] / (d["ms_per_step"] * 1e-3 * 45)) < 1e-6 * d["value"]
@@ -129,7 +133,7 @@ def test_bench_loop_world2_torchrun_env_gloo():
     outs = [p.communicate(timeout=300) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     d = _bench_line(outs[0][0])
-    assert d["n_gpus"] == 2 and d["env_steps_allreduced"] == 2 * 32 * 20
+    assert d["n_gpus"] == 2 and d["env_steps_allreduced"] == 2 * 32 * 20 and len(d["ranks_dt"]) == 2 and min(d["ranks_dt"]) > 0
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]      # rank 1 prints nothing
 
 

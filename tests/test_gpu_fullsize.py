@@ -261,7 +261,7 @@ def test_configs3_wfc_dr_8192_full_size():
     model = mjcf.load_model("stairs")
 
     def build(cnt, off, layout=None):
-        out = domain_randomize(model, cnt, seed=3, terrain=terrain, env_id_offset=off)
+        out = domain_randomize(model, cnt, seed=3, terrain=terrain, env_id_offset=off, total_envs=n)
         return Joystick("stairs", configs.training_config(), num_envs=cnt, terrain=terrain, device="cuda:0", autoreset=True, env_id_offset=off, layout=layout,
                         variant=torch.from_numpy(out["variant"]), params=torch.from_numpy(out["params"]), box_friction=torch.from_numpy(out["box_friction"])), out
 

@@ -478,3 +478,135 @@ def test_more_penetrating_boxes_than_tracked_per_foot(which):
             env.close()
         finally:
             EXEC["layout"] = None
+
+
+def _quat_mul(a, b):
+    w1, x1, y1, z1 = a; w2, x2, y2, z2 = b
+    return [w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2]
+
+
+def _tilt_quat(yaw_deg, tilt_deg, about_y):
+    """yaw about z, then a pitch (about the box's y) or a roll (about its x): the free quaternion a terrain row may carry
+    (go2/randomize.py:97-108 copies pos AND quat of every box; terrain_scene_mjx.xml:20-21)"""
+    y, t = np.deg2rad(yaw_deg) / 2, np.deg2rad(tilt_deg) / 2
+    qt = [np.cos(t), 0.0, np.sin(t), 0.0] if about_y else [np.cos(t), np.sin(t), 0.0, 0.0]
+    return _quat_mul([np.cos(y), 0.0, 0.0, np.sin(y)], qt)
+
+
+def ramp_terrain():
+    """Boxes that are NOT yaw-only: a 4 x 3 field of ramp tiles, pitched or rolled by 5 .. 25 degrees, two thirds of them also yawed, each overlapping
+    its neighbours by 5 - 10 cm, the low edge of every tile below the floor plane (so plane and box contacts coexist) and the high edge 5 - 20 cm above
+    it.  The sphere-box narrow phase then works in a rotated box frame (face selection among tilted faces, edge contacts along the ridge lines where
+    two tiles meet), the grid cull sees world AABBs that are larger than the boxes, and the scan hits tilted tops."""
+    T = []
+    for v in range(4):
+        rows, k = [], 0
+        for i in range(4):
+            for j in range(3):
+                tilt = 5.0 + 20.0 * ((k * 7 + 3 * v) % 12) / 11.0
+                yaw = 0.0 if k % 3 == 0 else (35.0 * k + 10.0 * v) % 360.0
+                q = _tilt_quat(yaw, tilt if (k + v) % 2 == 0 else -tilt, about_y=(k % 2 == 0))
+                rows.append([(i - 1.5) * 0.70 + 0.03 * v, (j - 1.0) * 0.60, -0.02 + 0.01 * (k % 3), *q, 0.40, 0.35, 0.05])
+                k += 1
+        rows += [[100.0 + n, 100.0 + n, 100.0 + n, 1, 0, 0, 0, 0.5, 0.5, 0.5] for n in range(100 - len(rows))]
+        T.append(rows)
+    return np.asarray(T, dtype=np.float32)
+
+
+def ramp_pile_terrain():
+    """Nine slabs piled over the spawn area, every one yawed AND tilted (0.3 .. 1.5 degrees about alternating axes), their centres on a 0.15 m ring at
+    the same height: half a metre out the nine top faces are 1 - 12 mm apart, so a standing foot (5 - 15 mm inside the highest one) is inside five to
+    nine rotated boxes at once and the narrow phase runs through the exact many-box pass - on boxes whose frames are general rotations."""
+    T = []
+    for v in range(4):
+        rows = []
+        for k in range(9):
+            r, phi = (0.0, 0.0) if k == 8 else (0.15, 2 * np.pi * k / 8 + 0.2 * v)
+            q = _tilt_quat(40.0 * k + 15.0 * v, (0.3 + 0.15 * k) * (1 if k % 3 else -1), about_y=(k % 2 == 0))
+            rows.append([r * np.cos(phi), r * np.sin(phi), 0.02, *q, 2.0, 1.8, 0.03])
+        rows += [[100.0 + n, 100.0 + n, 100.0 + n, 1, 0, 0, 0, 0.5, 0.5, 0.5] for n in range(100 - len(rows))]
+        T.append(rows)
+    return np.asarray(T, dtype=np.float32)
+
+
+def test_tilted_box_contact_parity(layout):
+    """MJX collides a sphere with a box of ANY orientation, the terrain table carries a free quaternion per box (go2/randomize.py:97-108,
+    go2/xmls/terrain_scene_mjx.xml:20-21) and pgtt_set_terrain accepts it - every other contact-parity terrain of this suite is yaw 0 / 90 / 180.
+    Ramps through the full parity bar (state, ACTIVE contact set, flags, scan) in all three lane layouts."""
+    terrain = ramp_terrain()
+    mats = terrain[:, :12, 3:7]
+    assert (np.abs(mats[..., 1]) + np.abs(mats[..., 2]) > 0.04).all()          # every placed box really is pitched or rolled
+    st = run_parity("stairs", 192, terrain, steps=30, w_floor=0.55, cap_scale=2.0, med_tol=4e-6)
+    assert st["box_contacts"] > 1500 and st["box_contacts"] > 0.25 * st["active_contacts"]
+    assert st["well_set_mismatch"] <= 2 and st["well_flag_mismatch"] <= 1
+
+
+def test_tilted_box_many_box_pass_parity(layout):
+    """the exact many-box pass (more than four penetrating boxes per foot) on rotated boxes: ACTIVE set = the oracle's on W, in every layout"""
+    terrain = ramp_pile_terrain()
+    n = 128
+    env, hb, cs, ms = make_pair("stairs", n, terrain)
+    h64 = oracle.HostBuffers(n, with_variant=True); h64["variant"][...] = hb["variant"]
+    env.reset(3); oracle.reset(cs, ms, terrain, hb, seed=3, nthreads=8)
+    rng = np.random.default_rng(1)
+    well_total = mism = flagged = total = deep_pairs = flag_mism = 0
+    for k in range(12):
+        sync_to_host(env, hb, h64)
+        act = np.tanh(rng.normal(size=(n, 12)) * 0.3).astype(np.float32)
+        env.step(torch.from_numpy(act).cuda())
+        r64 = np.zeros(n)
+        oracle.step(cs, ms, terrain, hb, act, seed=3, nthreads=8)
+        oracle.step(cs, ms, terrain, h64, act, seed=3, nthreads=8, fp64=True, resid=r64)
+        torch.cuda.synchronize()
+        g = {kk: v.cpu().numpy() for kk, v in env.buffers.items()}
+        assert all(np.isfinite(g[kk]).all() for kk in ("state", "frame", "obs_state", "obs_priv", "reward", "metrics", "scan_z"))
+        assert np.array_equal(g["istate"], hb["istate"])
+        ef = per_env_errors(hb.arrays, h64)
+        eg = per_env_errors(g, hb)
+        well = (r64 < 1e-6) & (ef["qpos"] < 1e-5) & (ef["qvel"] < 1e-3)
+        ga, ha = active_sets(g["dbg_contact"], g["dbg_dist"]), active_sets(hb["dbg_contact"], hb["dbg_dist"])
+        sm = np.array([a != b for a, b in zip(ga, ha)])
+        fl = (g["dbg_niter"] & 0x10000) != 0
+        mism += int((sm & well).sum()); well_total += int(well.sum()); flagged += int(fl.sum()); total += n
+        fc_g, fc_h = g["frame"][abi.F_CONTACT:abi.F_CONTACT + 4], hb["frame"][abi.F_CONTACT:abi.F_CONTACT + 4]
+        flag_mism += int(((fc_g != fc_h).any(0) & well).sum())
+        deep_pairs += sum(1 for a in ha for (_, b) in a if b >= 0)
+        assert (eg["qpos"][well] > 1e-4).sum() <= max(1, 0.01 * well.sum()), (k, eg["qpos"][well].max())
+        assert (eg["scan"][well] > 1e-5).sum() <= 1          # a ray next to a slab's side face may land on the other side of it (a step of the scan, not an error)
+    print(layout, "env-steps", total, "took the many-box pass", flagged, "| in W", well_total, ": ACTIVE-set mismatches", mism, "| flag mismatches", flag_mism, "| oracle box contacts", deep_pairs)
+    assert flagged > 0.5 * total and deep_pairs > 3 * total and well_total > 0.25 * total
+    assert mism <= 1 and flag_mism <= 1
+    env.close()
+
+
+def test_variant_label_out_of_range_is_an_error_not_a_fault():
+    """the boundary promises integer error codes, never a GPU fault: a terrain-variant label outside [0, T) makes pgtt_reset return PGTT_E_ARG before
+    it writes anything, and a step taken with such a label anyway (labels edited after the reset) runs on the clamped variant - no out-of-bounds read"""
+    from phase_guided_terrain_traversal_amd import native
+    from phase_guided_terrain_traversal_amd.env import Joystick
+    terrain = np.load(os.path.join(ASSETS, "terrains", "level4.npy"))
+    n, T = 64, terrain.shape[0]
+    for lay in ("hex", "oct", "quad"):
+        good = np.random.default_rng(0).integers(0, T, n).astype(np.int32)
+        env = Joystick("stairs", configs.training_config(), num_envs=n, terrain=terrain, device="cuda:0", variant=torch.from_numpy(good), layout=lay)
+        env.reset(1)
+        before = env.buffers["state"].clone()
+        for bad_value in (T, -1, 2 ** 30):
+            env.buffers["variant"][5] = bad_value
+            with pytest.raises(native.PgttError, match="variant label"):
+                env.reset(1)
+            assert torch.equal(env.buffers["state"], before)                      # nothing was written
+        # stepping with the bad labels in place: clamped to the last / first variant, bit-identical to an env that carries the clamped labels
+        env.buffers["variant"][5] = 2 ** 30; env.buffers["variant"][6] = -7
+        ref_lab = good.copy(); ref_lab[5] = T - 1; ref_lab[6] = 0
+        ref = Joystick("stairs", configs.training_config(), num_envs=n, terrain=terrain, device="cuda:0", variant=torch.from_numpy(ref_lab), layout=lay)
+        ref.reset(1)
+        for k in ("state", "istate"):
+            env.buffers[k].copy_(ref.buffers[k])
+        act = torch.tanh(torch.randn(n, 12, generator=torch.Generator().manual_seed(3)) * 0.5).cuda()
+        for _ in range(3):
+            env.step(act); ref.step(act)
+        torch.cuda.synchronize()
+        assert torch.isfinite(env.buffers["state"]).all()
+        assert torch.equal(env.buffers["state"][:55], ref.buffers["state"][:55]) and torch.equal(env.buffers["scan_z"], ref.buffers["scan_z"])
+        env.close(); ref.close()

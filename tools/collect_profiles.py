@@ -55,5 +55,10 @@ for T, key in (("flat", "flat_4096"), ("wfc_dr_8192", "wfc_dr_8192"), ("level4_u
         txt = open(f).read()
         open(os.path.join(dst, f"{tag}_{T}_pmc_summary.txt"), "w").write(hdr.replace("4096 envs on level4", T) + txt)
         t[key] = entry(txt, f"{T}_pmc_summary.txt")
+# which kernel sources these counters belong to: bench.py withholds them ("profile_stale": true) when the library it times was built from others
+sys.path.insert(0, root)
+from phase_guided_terrain_traversal_amd import native
+t["_source"] = {"csrc_sha256": native.source_sha256(), "lib_sha256": native.library_sha256() if os.path.exists(native.LIB_PATH) else None, "tag": tag,
+                "what": "SHA-256 over csrc/*.hip, csrc/*.h, csrc/Makefile, include/*.h (native.source_sha256) at the time the counters were collected; lib_sha256 = libpgtt.so itself"}
 json.dump(t, open(tp, "w"), indent=1)
-print("collected", tag, {k: (round(v["physics_bytes_per_launch"] / 1e6, 2), round(v.get("valu_busy", 0), 3)) for k, v in t.items()})
+print("collected", tag, {k: (round(v["physics_bytes_per_launch"] / 1e6, 2), round(v.get("valu_busy", 0), 3)) for k, v in t.items() if not k.startswith("_")})
