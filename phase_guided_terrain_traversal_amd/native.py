@@ -24,14 +24,14 @@ class PgttError(RuntimeError):
 
 
 def source_sha256() -> str:
-    """SHA-256 over the sources libpgtt.so is built from (csrc/*.hip, csrc/*.h, csrc/Makefile, include/*.h; names and contents, sorted):
-    tools/collect_profiles.py stores it next to the rocprofv3 counters it commits, bench.py compares it before quoting them."""
-    import glob
+    """SHA-256 over the sources physics_kernel is built from - what the translation unit csrc/pgtt_physics_inst.hip includes, plus the Makefile
+    that holds its flags (names and contents, sorted): tools/collect_profiles.py stores it next to the rocprofv3 counters of that kernel,
+    bench.py compares it before quoting them."""
     import hashlib
     h = hashlib.sha256()
-    inc = os.path.join(os.path.dirname(_HERE), "include")
-    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) + [os.path.join(_HERE, "csrc", "Makefile")]
-                   + glob.glob(os.path.join(inc, "*.h")))
+    root = os.path.dirname(_HERE)
+    files = sorted([os.path.join(_HERE, "csrc", f) for f in ("pgtt_physics_inst.hip", "pgtt_physics.hip.h", "pgtt_physics_quad.hip.h", "pgtt_kernels.hip.h", "Makefile")]
+                   + [os.path.join(root, "include", "pgtt.h")])
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:

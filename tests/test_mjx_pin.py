@@ -413,13 +413,15 @@ def test_hip_one_mjx_step_against_fixture(pin, layout):
             S = b["state"][:, e].astype(np.float64)
             eq, ev = np.abs(S[0:19] - pin(grp, "mjx_qpos")[e]).max(), np.abs(S[19:37] - pin(grp, "mjx_qvel")[e]).max()
             w = np.asarray(pin(grp, "mjx_qacc_warmstart")[e], np.float64)
-            ew = (np.abs(S[37:55] - w) / (1 + np.abs(w))).max()
+            # relative to the size of the acceleration VECTOR: the crafted deep-penetration cases have |qacc| ~ 400, where a per-component relative error
+            # of 1e-2 is what the oracle's own fp32 build shows against its fp64 build (8e-5 of the vector's magnitude)
+            ew = np.abs(S[37:55] - w).max() / (1 + np.abs(w).max())
             mine = {(int(f), int(bb)): float(dd) for (f, bb), dd in zip(con[e], dist[e]) if bb != -2}
             sens = frame_from_sensordata(np.asarray(pin(grp, "mjx_sensordata")[e], np.float64), np.asarray(pin(grp, "mjx_actuator_force")[e], np.float64))
             es = (np.abs(b["frame"][FRAME_ROWS, e] - sens) / (1 + np.abs(sens))).max()
             tot["cases"] += 1
             if conv:
-                tot["conv"] += 1; tot["bad_q"] += eq > 1e-4; tot["bad_v"] += ev > 1e-4 / 0.005; tot["bad_w"] += ew > 1e-2
+                tot["conv"] += 1; tot["bad_q"] += eq > 1e-4; tot["bad_v"] += ev > 1e-4 / 0.005; tot["bad_w"] += ew > 1e-3
                 tot["bad_set"] += active(mine) != active(fc[e]); tot["bad_sens"] += es > 1e-2
         assert np.isfinite(b["state"]).all()
         env.close()

@@ -59,6 +59,6 @@ for T, key in (("flat", "flat_4096"), ("wfc_dr_8192", "wfc_dr_8192"), ("level4_u
 sys.path.insert(0, root)
 from phase_guided_terrain_traversal_amd import native
 t["_source"] = {"csrc_sha256": native.source_sha256(), "lib_sha256": native.library_sha256() if os.path.exists(native.LIB_PATH) else None, "tag": tag,
-                "what": "SHA-256 over csrc/*.hip, csrc/*.h, csrc/Makefile, include/*.h (native.source_sha256) at the time the counters were collected; lib_sha256 = libpgtt.so itself"}
+                "what": "SHA-256 over the sources of physics_kernel (csrc/pgtt_physics_inst.hip and the headers it includes, csrc/Makefile, include/pgtt.h: native.source_sha256) at the time the counters were collected; lib_sha256 = libpgtt.so itself"}
 json.dump(t, open(tp, "w"), indent=1)
 print("collected", tag, {k: (round(v["physics_bytes_per_launch"] / 1e6, 2), round(v.get("valu_busy", 0), 3)) for k, v in t.items() if not k.startswith("_")})
