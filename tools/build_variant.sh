@@ -5,7 +5,7 @@ set +m
 out=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 cd $root/phase_guided_terrain_traversal_amd/csrc
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -fno-hip-fp32-correctly-rounded-divide-sqrt $*"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $*"
 mkdir -p $root/alt_build/$out
 for v in 1_0_0_0 1_0_0_1 1_0_1_0 1_0_1_1 1_1_0_0 1_1_0_1 1_1_1_0 1_1_1_1 4_0_0_0 4_0_0_1 4_0_1_0 4_0_1_1 4_1_0_0 4_1_0_1 4_1_1_0 4_1_1_1 2_0_0_0 2_0_0_1 2_0_1_0 2_0_1_1 2_1_0_0 2_1_0_1 2_1_1_0 2_1_1_1; do
   IFS=_ read s m d t <<< "$v"

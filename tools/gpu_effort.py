@@ -43,6 +43,10 @@ for t in range(1, len(rec)):
         c, _, _ = cost(rec[t], np.argsort(key, kind="stable")); tot[name].append(c.max()); tot[name + "_mean"] = tot.get(name + "_mean", []) + [c.mean()]
     tot["alone"].append(own(rec[t]).mean())
 print(f"{wl}: {len(rec) - 1} control steps of {n} envs; wave of {G} envs: Newton trips {np.mean(tr):.2f}, line-search rounds {np.mean(rd):.1f} per control step (fixed grouping)")
+# histogram of the Newton trips an env needs in ONE substep (5 = the cap of go2_mjx_feetonly.xml:17): what a "main pass of k trips + compacted tail pass" would leave for the tail
+per_sub = (rec.reshape(-1, n, 4, 5) > 0).sum(3).ravel()
+hist = np.bincount(per_sub, minlength=6) / per_sub.size
+print("  Newton trips of an env in one substep: " + "  ".join(f"{k}: {100 * hist[k]:.1f} %" for k in range(6)) + f"   -> needs trips 4 - 5: {100 * hist[4:].sum():.1f} % of env-substeps")
 print(f"  an env on its own: trips {(rec > 0).sum(2).mean():.2f}, rounds {np.maximum(rec - 1, 0).sum(2).mean():.1f}; solver ticks {np.mean(tot['alone']):.0f}")
 for k in ("fixed", "sorted", "oracle"):
     print(f"  {k:7s}: solver ticks of the mean wave {np.mean(tot[k + '_mean']):9.0f}   of the slowest wave {np.mean(tot[k]):9.0f}")
