@@ -39,7 +39,7 @@ struct TerrainBox {                 // resident terrain table entry (80 B), buil
 // compiler kept the ~50 row addresses of the prologue alive until the stores (scratch in the oct layout: 18 of its 39 spilled dwords were address
 // pairs) rather than redo a 64-bit multiply.  Valid while 4 * rows * N < 2^32 (pgtt_create refuses more envs).  The hex layout keeps the 64-bit
 // forms it was tuned with: there the change moved code across fp-contraction decisions (results at rounding distance from the build before it)
-// without a gain (round 4).
+// without a gain (round 4, docs/HISTORY.md 5.7).
 #if defined(PG_SUBS) && PG_SUBS == 4
 #define PG_ADDR32 0
 #else

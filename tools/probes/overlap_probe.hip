@@ -1,4 +1,4 @@
-// Probe: can the observe launch of a step run in the TAIL of the physics launch?  
+// Probe: can the observe launch of a step run in the TAIL of the physics launch?  (docs/HISTORY.md 5.6)
 // physics_kernel holds one wave per SIMD with all 512 registers, its waves finish between ~0.92 and 1.0 of the launch, and the observe
 // launch (one wave per env, 128 registers, four per SIMD) may only start when the last physics wave has left.  Here: kernel P = 1024 waves,
 // one per SIMD (amdgpu_waves_per_eu(1,1)), each busy for 100 + (0..20) us, then it publishes its 4 "envs" (data rows, release fence, queue
