@@ -362,6 +362,22 @@ def test_library_refuses_without_bind():
     L.pgtt_destroy(h)
 
 
+def test_terrain_table_beyond_32_bit_offsets_is_refused():
+    """the quad / oct kernels address the terrain table and the cell grid through 32-bit byte offsets from their bases: a table that does not fit is a
+    PGTT_E_ARG of pgtt_set_terrain (checked before the table is read), not a wrapped offset"""
+    import ctypes as C
+    from phase_guided_terrain_traversal_amd import native
+    L = native.lib()
+    cs = abi.config_struct(configs.default_config()); ms = abi.model_struct(mjcf.load_model("stairs"))
+    h = C.c_void_p()
+    native.check(L.pgtt_create(C.byref(cs), C.byref(ms), 0, 64, C.byref(h)))
+    tiny = np.zeros((1, 100, 10), np.float32)
+    assert L.pgtt_set_terrain(h, tiny.ctypes.data, 600000, 100) == -1 and b"too large" in L.pgtt_last_error()         # 600 000 x 100 x 80 B = 4.8 GB
+    assert L.pgtt_set_terrain(h, tiny.ctypes.data, 1100000, 1) == -1 and b"too large" in L.pgtt_last_error()          # the grid: 1.1 M x 4096 B
+    assert L.pgtt_set_terrain(h, tiny.ctypes.data, 1, 100) == 0
+    L.pgtt_destroy(h)
+
+
 def dense_terrain():
     """Terrain on which MJX's broad-phase top-k (max_geom_pairs = 25) REALLY truncates: 90 tiny 2 x 2 cm tiles
     (2 mm high, 4 cm pitch) cluster their centres around the spawn area, while ten long slabs (3 cm high) have their
