@@ -35,8 +35,9 @@ if sys.argv[1] == "--child":
             run(f"{wl}_{lay}", "flat_terrain" if wl == "flat" else "stairs", n, terrain, lay, **kw)
     t13 = np.load(A + "level13.npy"); n = 1000
     dr = domain_randomize(mjcf.load_model("stairs"), n, seed=3, terrain=t13)
-    run("level13_dr_ragged", "stairs", n, t13, "hex", cfg=configs.with_overrides(configs.training_config(), episode_length=17),
-        variant=torch.from_numpy(dr["variant"]), params=torch.from_numpy(dr["params"]), box_friction=torch.from_numpy(dr["box_friction"]))
+    for lay in ("hex",) + (("oct", "quad") if os.environ.get("PGTT_AB_OCT") else ()):          # the DR + terrain kernels of every layout
+        run("level13_dr_ragged" + ("" if lay == "hex" else "_" + lay), "stairs", n, t13, lay, cfg=configs.with_overrides(configs.training_config(), episode_length=17),
+            variant=torch.from_numpy(dr["variant"]), params=torch.from_numpy(dr["params"]), box_friction=torch.from_numpy(dr["box_friction"]))
     np.savez(out, **res)
     sys.exit(0)
 a, b = sys.argv[1], sys.argv[2]
