@@ -5,10 +5,10 @@ reads them, the compiled MuJoCo model's constants - against the CPU oracle (floa
 Two fixtures go through the SAME checks:
   * `mjx`     tests/golden/mjx_step.npz - produced on a machine that has mujoco / mujoco-mjx / playground.  It does not exist
               in this repository yet (none of those packages is installable in the build container): every test SKIPS for it.
-  * `dry_run` the same recorder with the oracle standing in for mjx, generated into a temporary folder by the test session.  It pins nothing about
-              MJX; it proves that the file layout, the raw-MuJoCo-field -> PgttBuffers conversion, the geom-id -> (foot, box) mapping
-              (go2/base.py:87-105; the dry run numbers its geoms differently from the real model on purpose) and the comparison code work, so that the
-              first real file is checked by code that has run.
+  * `dry_run` the same recorder running on stand-in jax / mujoco / mjx / reference modules (tools/fake_mjx.py) with the oracle doing the arithmetic,
+              generated into a temporary folder by the test session.  It pins nothing about MJX; it proves that the recorder's calls, the file layout, the
+              raw-MuJoCo-field -> PgttBuffers conversion, the geom-id -> (foot, box) mapping (go2/base.py:87-105; the stand-ins number their geoms
+              differently from the real model on purpose) and the comparison code work, so that the first real file comes from, and is checked by, code that has run.
 Bars (north star): float32 state within 1e-4 after the step (qvel: 1e-4 / dt), ACTIVE (foot, geom) contact set identical, on the cases whose Newton
 solve stops before the 5-iteration cap in the float64 oracle (DESIGN.md 3: a solve that is cut returns a point that depends on rounding, in MJX too);
 the real fixture may miss them on 2 % of those cases (fp32 MJX against fp64), the dry run on none.

@@ -1,0 +1,338 @@
+"""Stand-ins for `jax`, `mujoco`, `mujoco.mjx`, `mujoco_playground._src.mjx_env` and the reference's `go2.configs / go2.joystick_pgtt /
+go2.randomize` modules, with the repo's CPU oracle doing the arithmetic - the DRY RUN of tools/gen_golden_mjx.py.
+
+Purpose: `gen_golden_mjx.MjxBackend` - the code that will talk to the real MJX on a machine that has it - cannot run in the build container.  With these
+modules injected it runs here UNCHANGED (same calls: jax.random.split / vmap / jit, Joystick(task, config), domain_randomize(model, keys, terrain_matrix),
+env.reset / env.step on shallow copies with a per-env model, mjx.step on data.replace(ctrl=...), State / Data `.replace`, the batched Model's raw
+MuJoCo fields, contact.geom / contact.dist, MjModel accessors), so every attribute name, shape and call sequence of the recorder is executed in every test
+session, and the file it writes goes through the same tests as a real one.  The stand-ins keep MuJoCo's data model - per-env model fields under MuJoCo's names
+and shapes, geoms / bodies / sites addressed by integer ids - but number things DIFFERENTLY from the real compiled model (floor 0, feet 27 / 31 / 35 / 38,
+boxes from geom 40 / body 20; the real model: boxes from geom 57 / body 14, go2/randomize.py:24-25), so nothing downstream can rely on hard-coded ids.
+
+This pins NOTHING about MJX: the numbers come from oracle.forward (one mjx.forward + Euler) and oracle.step (Joystick.step), float64.
+Test infrastructure: imported only by tools/gen_golden_mjx.py --dry-run (and through it by tests/test_mjx_pin.py); never by the product."""
+from __future__ import annotations
+
+import copy
+import os
+import sys
+import types
+from typing import Any, Dict
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from oracle import oracle                                                            # noqa: E402
+from phase_guided_terrain_traversal_amd import abi, configs, mjcf, randomize       # noqa: E402
+
+FEET = ["FR", "FL", "RR", "RL"]
+LEGS = ["FL", "FR", "RL", "RR"]
+NBODY_BOX0, NGEOM_BOX0 = 20, 40
+FEET_GEOM = {"FR": 31, "FL": 27, "RR": 38, "RL": 35}
+NB, NG = NBODY_BOX0 + abi.MAX_BOX, NGEOM_BOX0 + abi.MAX_BOX
+DR_FIELDS = ["geom_friction", "body_ipos", "body_mass", "qpos0", "dof_frictionloss", "dof_armature", "dof_damping", "actuator_gainprm",
+             "actuator_biasprm", "body_pos", "body_quat", "geom_size"]
+INFO_ROWS = (("command", abi.S_CMD, 3), ("phase", abi.S_PHASE, 4), ("last_act", abi.S_LAST_ACT, 12), ("last_last_act", abi.S_LAST_LAST_ACT, 12),
+             ("feet_air_time", abi.S_AIR_TIME, 4), ("swing_peak", abi.S_SWING_PEAK, 4), ("H_max", abi.S_HMAX, 4), ("H_min", abi.S_HMIN, 4),
+             ("motor_targets", abi.S_MOTOR_TARGETS, 12), ("qpos_error_history", abi.S_QERR_HIST, 24), ("qvel_history", abi.S_QVEL_HIST, 24))
+
+
+# ---------------------------------------------------------------------------------------------------------------------- pytrees
+class Struct:
+    """attribute bag with the `.replace` of a flax / mjx dataclass and the `.tree_replace` of mjx.Model"""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def replace(self, **kw):
+        c = copy.copy(self); c.__dict__ = dict(self.__dict__); c.__dict__.update(kw)
+        return c
+
+    def tree_replace(self, d):
+        return self.replace(**d)
+
+
+def _is_leaf(x):
+    return not isinstance(x, (Struct, dict))
+
+
+def tree_slice(x, ax, i):
+    """element i of the leaves whose in_axes entry is 0; `ax` is None / 0 for the whole subtree or a tree of the same shape"""
+    if isinstance(x, Struct):
+        return type(x)(**{k: tree_slice(v, getattr(ax, k) if isinstance(ax, Struct) else ax, i) for k, v in x.__dict__.items()})
+    if isinstance(x, dict):
+        return {k: tree_slice(v, ax[k] if isinstance(ax, dict) else ax, i) for k, v in x.items()}
+    if ax is None or x is None or np.ndim(x) == 0 and not isinstance(x, np.ndarray):
+        return x
+    return np.asarray(x)[i]
+
+
+def tree_stack(items):
+    x = items[0]
+    if isinstance(x, Struct):
+        return type(x)(**{k: tree_stack([getattr(it, k) for it in items]) for k in x.__dict__})
+    if isinstance(x, dict):
+        return {k: tree_stack([it[k] for it in items]) for k in x}
+    if x is None:
+        return None
+    return np.stack([np.asarray(it) for it in items])
+
+
+def tree_len(x, ax):
+    if isinstance(x, Struct):
+        for k, v in x.__dict__.items():
+            n = tree_len(v, getattr(ax, k) if isinstance(ax, Struct) else ax)
+            if n is not None:
+                return n
+        return None
+    if isinstance(x, dict):
+        for k, v in x.items():
+            n = tree_len(v, ax[k] if isinstance(ax, dict) else ax)
+            if n is not None:
+                return n
+        return None
+    return None if (ax is None or x is None or np.ndim(x) == 0) else int(np.shape(x)[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------------- jax
+def make_jax():
+    jax = types.ModuleType("jax")
+
+    def vmap(f, in_axes=0):
+        def g(*args):
+            axes = in_axes if isinstance(in_axes, (tuple, list)) else (in_axes,) * len(args)
+            n = next(m for m in (tree_len(a, ax) for a, ax in zip(args, axes)) if m is not None)
+            return tree_stack([f(*[tree_slice(a, ax, i) for a, ax in zip(args, axes)]) for i in range(n)])
+        return g
+    jax.vmap = vmap
+    jax.jit = lambda f=None, **k: (f if f is not None else (lambda h: h))
+    jax.device_get = lambda x: x
+    jax.default_backend = lambda: "fake (oracle behind stand-in modules)"
+    jax.config = types.SimpleNamespace(update=lambda *a, **k: None)
+    rnd = types.ModuleType("jax.random")
+    rnd.PRNGKey = lambda seed: np.array([0, int(seed)], dtype=np.uint32)
+    rnd.split = lambda key, n=2: np.stack([np.array([int(key[1]) % 65521, (int(key[1]) * 1000003 + 7919 * (i + 1)) % (2 ** 31)], dtype=np.uint32) for i in range(n)])
+    jax.random = rnd
+    jax.tree_util = types.SimpleNamespace(tree_map=lambda f, t: type(t)(**{k: f(v) for k, v in t.__dict__.items()}))
+    return jax, np            # jax.numpy: numpy has every function the recorder calls (asarray, broadcast_to, zeros_like, full_like, stack)
+
+
+# ---------------------------------------------------------------------------------------------------------------------- the compiled model
+class AttrDict(dict):
+    """ml_collections.ConfigDict as far as the recorder uses it: attribute access on a nested dict"""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def _attr(d):
+    return AttrDict({k: (_attr(v) if isinstance(v, dict) else v) for k, v in d.items()})
+
+
+def floor_ids(task):
+    return [0] + ([NGEOM_BOX0 + b for b in range(abi.MAX_BOX)] if task == "stairs" else [])
+
+
+def mj_model(task: str) -> Struct:
+    """MuJoCo's MjModel as far as the recorder reads it, filled from the repo's compiled constants (mjcf.load_model) under MuJoCo's names and shapes"""
+    m = mjcf.load_model(task)
+    A = lambda k: np.asarray(m[k], dtype=np.float64)
+    mm = Struct(opt=Struct(timestep=A("timestep"), gravity=A("gravity"), impratio=A("impratio"), tolerance=A("tolerance"), ls_tolerance=A("ls_tolerance"),
+                           iterations=np.asarray(m["iterations"]), ls_iterations=np.asarray(m["ls_iterations"]), cone=np.asarray(0), jacobian=np.asarray(0),
+                           solver=np.asarray(2), integrator=np.asarray(0), disableflags=np.asarray(0)),
+                stat=Struct(meaninertia=A("meaninertia")), nbody=NB, ngeom=NG, nsensor=0, _numeric={"max_contact_points": A("max_contact_points"), "max_geom_pairs": A("max_geom_pairs")},
+                _key=A("key_qpos"), _src=m)
+
+    def bodies(k, width, fill=0.0):
+        a = np.full((NB,) + ((width,) if width else ()), fill); a[1:14] = A(k); return a
+    for k, w in (("body_mass", 0), ("body_inertia", 3), ("body_ipos", 3), ("body_iquat", 4), ("body_pos", 3), ("body_quat", 4), ("body_invweight0", 2)):
+        setattr(mm, k, bodies(k, w))
+    mm.body_quat[14:, 0] = 1.0; mm.body_iquat[14:, 0] = 1.0; mm.body_quat[0, 0] = 1.0; mm.body_iquat[0, 0] = 1.0
+    mm.body_parentid = np.zeros(NB, int)
+    for k in ("dof_invweight0", "dof_armature", "dof_damping", "qpos0"):
+        setattr(mm, k, A(k))
+    mm.dof_frictionloss = np.zeros(18)
+    mm.jnt_range = np.vstack([np.zeros((1, 2)), A("jnt_range")]); mm.jnt_axis = np.vstack([np.zeros((1, 3)), A("jnt_axis")]); mm.jnt_type = np.array([0] + [3] * 12)
+    mm.jnt_solref = np.tile(A("jnt_solref"), (13, 1)); mm.jnt_solimp = np.tile(A("jnt_solimp"), (13, 1))
+    gain = np.zeros((12, 10)); gain[:, 0] = A("act_gain"); bias = np.zeros((12, 10)); bias[:, :3] = A("act_bias")
+    mm.actuator_gainprm, mm.actuator_biasprm = gain, bias
+    mm.actuator_ctrlrange, mm.actuator_forcerange = A("act_ctrlrange"), A("act_forcerange")
+    mm.actuator_trnid = np.stack([np.asarray(m["act_dof"]) - 6 + 1, np.full(12, -1)], axis=1)          # joint ids: free joint 0, hinges 1 .. 12
+    for k, w in (("geom_friction", 3), ("geom_solref", 2), ("geom_solimp", 5), ("geom_margin", 0), ("geom_gap", 0), ("geom_solmix", 0), ("geom_condim", 0),
+                 ("geom_size", 3), ("geom_pos", 3), ("geom_rbound", 0), ("geom_bodyid", 0), ("geom_type", 0), ("geom_contype", 0), ("geom_conaffinity", 0), ("geom_group", 0)):
+        setattr(mm, k, np.zeros((NG,) + ((w,) if w else ())))
+    mm.geom_quat = np.zeros((NG, 4)); mm.geom_quat[:, 0] = 1.0
+    for kind, gl in [("floor", [0])] + [("foot", [FEET_GEOM[f]]) for f in FEET] + [("box", list(range(NGEOM_BOX0, NG)))]:
+        for g in gl:
+            for k in ("friction", "solref", "solimp", "margin", "gap", "solmix", "condim"):
+                getattr(mm, "geom_" + k)[g] = A(f"{kind}_{k}")
+    for f in FEET:
+        leg, g = LEGS.index(f), FEET_GEOM[f]
+        mm.geom_size[g, 0] = A("foot_radius")[leg]; mm.geom_pos[g] = A("foot_geom_pos")[leg]; mm.geom_bodyid[g] = 1 + 3 * leg + 2 + 1; mm.geom_rbound[g] = A("foot_radius")[leg]
+    mm.geom_rbound[NGEOM_BOX0:] = A("box_rbound"); mm.geom_bodyid[NGEOM_BOX0:] = np.arange(NBODY_BOX0, NB); mm.geom_size[NGEOM_BOX0:] = 0.5
+    mm.site_pos = np.zeros((5, 3)); mm.site_pos[0] = A("imu_pos"); mm.site_bodyid = np.array([1, 4, 7, 10, 13])
+    for leg in range(4):                                             # sites [imu, FL, FR, RL, RR] like the XML
+        mm.site_pos[1 + leg] = A("foot_site_pos")[leg]
+    mm.sensor_adr = np.zeros(0, int); mm.sensor_dim = np.zeros(0, int); mm.sensor_type = np.zeros(0, int)
+    mm.keyframe = lambda name: Struct(qpos=mm._key)
+    mm.numeric = lambda name: Struct(data=mm._numeric[name])
+    return mm
+
+
+def put_model(mm: Struct) -> Struct:
+    """mjx.put_model: the fields a randomization_fn may batch (go2/randomize.py:150-163) - and nothing else the recorder touches"""
+    return Struct(**{k: np.array(getattr(mm, k), dtype=np.float64) for k in DR_FIELDS}, nbody=mm.nbody)
+
+
+def env_inputs(model: Struct, task: str):
+    """ONE env's model in MuJoCo's layout -> (params[77], boxes (B, 10) or None, box_friction or None) of the oracle / PgttBuffers"""
+    P = np.zeros(abi.NPARAM, np.float32)
+    P[abi.P_BODY_MASS:abi.P_BODY_MASS + 13] = model.body_mass[1:14]; P[abi.P_BASE_IPOS:abi.P_BASE_IPOS + 3] = model.body_ipos[1]
+    P[abi.P_QPOS0:abi.P_QPOS0 + 12] = model.qpos0[7:]; P[abi.P_ARMATURE:abi.P_ARMATURE + 12] = model.dof_armature[6:]
+    P[abi.P_DAMPING:abi.P_DAMPING + 12] = model.dof_damping[6:]; P[abi.P_GAIN:abi.P_GAIN + 12] = model.actuator_gainprm[:, 0]
+    P[abi.P_BIAS1:abi.P_BIAS1 + 12] = model.actuator_biasprm[:, 1]; P[abi.P_FLOOR_FRICTION] = model.geom_friction[0, 0]
+    if task != "stairs":
+        return P, None, None
+    bb, gg = slice(NBODY_BOX0, NB), slice(NGEOM_BOX0, NG)
+    boxes = np.concatenate([model.body_pos[bb], model.body_quat[bb], model.geom_size[gg]], axis=1).astype(np.float32)
+    return P, boxes, model.geom_friction[gg, 0].astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------- go2.randomize
+def make_randomize(task_of_model):
+    mod = types.ModuleType("go2.randomize")
+
+    def domain_randomize(model: Struct, rng, terrain_matrix):
+        """go2/randomize.py:23 signature; draws from the repo's own host function (distributions of SURVEY A1.6), variants in draw order"""
+        n, terr = len(rng), np.asarray(terrain_matrix, dtype=np.float32)
+        out = randomize.domain_randomize(mjcf.load_model("stairs"), n, seed=int(rng[0][1]), terrain=terr, group_variants=False)
+        P = out["params"].astype(np.float64)
+        rep = lambda a: np.repeat(np.asarray(a, np.float64)[None], n, 0)
+        f = {k: rep(getattr(model, k)) for k in DR_FIELDS}
+        f["body_mass"][:, 1:14] = P[abi.P_BODY_MASS:abi.P_BODY_MASS + 13].T; f["body_ipos"][:, 1] = P[abi.P_BASE_IPOS:abi.P_BASE_IPOS + 3].T
+        f["qpos0"][:, 7:] = P[abi.P_QPOS0:abi.P_QPOS0 + 12].T; f["dof_armature"][:, 6:] = P[abi.P_ARMATURE:abi.P_ARMATURE + 12].T
+        f["dof_damping"][:, 6:] = P[abi.P_DAMPING:abi.P_DAMPING + 12].T; f["actuator_gainprm"][:, :, 0] = P[abi.P_GAIN:abi.P_GAIN + 12].T
+        f["actuator_biasprm"][:, :, 1] = P[abi.P_BIAS1:abi.P_BIAS1 + 12].T
+        boxes = terr[out["variant"]].astype(np.float64); B = boxes.shape[1]
+        f["body_pos"][:, NBODY_BOX0:NBODY_BOX0 + B] = boxes[..., 0:3]; f["body_quat"][:, NBODY_BOX0:NBODY_BOX0 + B] = boxes[..., 3:7]
+        f["geom_size"][:, NGEOM_BOX0:NGEOM_BOX0 + B] = boxes[..., 7:10]; f["geom_friction"][:, NGEOM_BOX0:NG, 0] = out["box_friction"].T
+        in_axes = Struct(**{k: (0 if k in DR_FIELDS else None) for k in model.__dict__})
+        return model.replace(**f), in_axes
+    mod.domain_randomize = domain_randomize
+    return mod
+
+
+# ---------------------------------------------------------------------------------------------------------------------- mjx + the env
+def _contact_struct(d: Dict[str, Any], seed: int) -> Struct:
+    """oracle contact list -> mjx Contact (geom pairs in the stand-in numbering; slot order shuffled: MJX's own order is not the oracle's)"""
+    geom = np.zeros((8, 2), np.int32); dist = np.ones(8); frame = np.zeros((8, 3, 3)); pos = np.zeros((8, 3))
+    for slot, k in enumerate(np.random.default_rng(seed).permutation(8)):
+        foot, box = int(d["con_foot"][k]), int(d["con_box"][k])
+        if box == -2:                         # unused slot: some pair with dist > 0, like MJX's non-penetrating candidates
+            geom[slot] = (0, FEET_GEOM["FR"]); continue
+        fg = FEET_GEOM[LEGS[foot]]
+        geom[slot] = (0, fg) if box == -1 else (fg, NGEOM_BOX0 + box)
+        dist[slot], frame[slot], pos[slot] = d["con_dist"][k], d["con_frame"][k], d["con_pos"][k]
+    return Struct(geom=geom, dist=dist, frame=frame, pos=pos)
+
+
+def make_mjx(task_ref):
+    mjx = types.ModuleType("mujoco.mjx")
+
+    def step(model: Struct, data: Struct) -> Struct:
+        """one mjx.step for ONE env (the recorder vmaps it): oracle.forward, float64"""
+        task = task_ref["task"]
+        P, boxes, bf = env_inputs(model, task)
+        ms = abi.model_struct(mjcf.load_model(task))
+        d = oracle.forward(ms, np.asarray(data.qpos, np.float64), np.asarray(data.qvel, np.float64), np.asarray(data.ctrl, np.float64),
+                           warm=np.asarray(data.qacc_warmstart, np.float64), boxes=boxes, box_friction=bf, params=P, fp64=True)
+        seed = int(abs(float(data.qpos[0])) * 1e6) % 9973
+        return data.replace(qpos=d["qpos_next"], qvel=d["qvel_next"], qacc_warmstart=d["qacc"], qacc=d["qacc"], sensordata=d["sensordata"],
+                            actuator_force=d["actuator_force"], qfrc_bias=d["qfrc_bias"], qfrc_passive=d["qfrc_passive"], qfrc_actuator=d["qfrc_actuator"],
+                            qfrc_constraint=d["qfrc_constraint"], qfrc_smooth=d["qfrc_smooth"], qacc_smooth=d["qacc_smooth"], efc_force=d["efc_force"],
+                            efc_D=d["efc_D"], efc_aref=d["efc_aref"], efc_pos=d["efc_pos"], xpos=d["xpos"], xquat=d["xquat"], subtree_com=d["com"][None],
+                            site_xpos=np.vstack([np.zeros((1, 3)), d["site_foot"][[1, 0, 3, 2]]]), site_xmat=np.stack([d["site_imu_mat"]] + [np.eye(3)] * 4),
+                            contact=_contact_struct(d, seed))
+    mjx.step = step
+    mjx.forward = lambda model, data: data          # derived quantities are recomputed by every step
+    mjx.put_model = put_model
+    return mjx
+
+
+class Joystick:
+    """go2.joystick_pgtt.Joystick (go2/joystick_pgtt.py:35-231, go2/base.py:45-113) as far as the recorder drives it; per-env semantics, vmapped outside"""
+
+    def __init__(self, task="flat_terrain", config=None, config_overrides=None):
+        self.task, self._config = task, config
+        self._mj_model = mj_model(task)
+        self._mjx_model = put_model(self._mj_model)
+        self._imu_site_id = 0
+        self._feet_site_id = np.array([1 + LEGS.index(f) for f in FEET])
+        self._feet_geom_id = np.array([FEET_GEOM[f] for f in FEET])
+        self._floor_geom_id = np.array(floor_ids(task))
+        TASK["task"] = task
+
+    mj_model = property(lambda self: self._mj_model)
+    mjx_model = property(lambda self: self._mjx_model)
+    dt = property(lambda self: self._config["ctrl_dt"])
+
+    def _oracle_args(self):
+        P, boxes, bf = env_inputs(self._mjx_model, self.task)
+        cs, ms = abi.config_struct(dict(self._config)), abi.model_struct(mjcf.load_model(self.task))
+        hb = oracle.HostBuffers(1, with_params=True, with_variant=boxes is not None, with_box_friction=boxes is not None)
+        hb["params"][:, 0] = P
+        if boxes is not None:
+            hb["box_friction"][:len(bf), 0] = bf
+        return cs, ms, (None if boxes is None else boxes[None]), hb
+
+    def _state(self, hb, rng, qacc_warm=None) -> Struct:
+        S, I = hb["state"][:, 0].astype(np.float64), hb["istate"][:, 0]
+        info = {name: S[off:off + cnt].copy() for name, off, cnt in INFO_ROWS}
+        info.update(step=np.int32(I[abi.I_STEP]), steps_until_next_cmd=np.int32(I[abi.I_STEPS_UNTIL_CMD]), phase_dt=S[abi.S_PHASE_DT], gait_freq=S[abi.S_GAIT_FREQ],
+                    last_contact=S[abi.S_LAST_CONTACT:abi.S_LAST_CONTACT + 4] > 0.5, rng=rng,
+                    heightscan=np.concatenate([np.zeros((13, 9, 2)), hb["scan_z"][0].astype(np.float64).reshape(13, 9, 1)], axis=2))
+        data = Struct(qpos=S[0:19].copy(), qvel=S[19:37].copy(), qacc_warmstart=S[37:55].copy(), ctrl=S[abi.S_MOTOR_TARGETS:abi.S_MOTOR_TARGETS + 12].copy())
+        metrics = {f"reward/{k}": np.float64(hb["metrics"][i, 0]) for i, k in enumerate(abi.REWARD_KEYS)}
+        metrics["swing_peak"] = np.float64(hb["metrics"][abi.NREW, 0])
+        return Struct(data=data, obs={"state": hb["obs_state"][0].astype(np.float64), "privileged_state": hb["obs_priv"][0].astype(np.float64)},
+                      reward=np.float64(hb["reward"][0]), done=np.float64(hb["done"][0]), metrics=metrics, info=info)
+
+    def reset(self, rng) -> Struct:
+        cs, ms, terrain, hb = self._oracle_args()
+        oracle.reset(cs, ms, terrain, hb, seed=int(rng[1]), nthreads=1, fp64=True)
+        s = self._state(hb, rng)
+        s.data.ctrl = s.data.qpos[7:].copy()                    # mjx_env.init(ctrl = qpos[7:]), joystick_pgtt.py:72
+        return s
+
+    def step(self, state: Struct, action) -> Struct:
+        cs, ms, terrain, hb = self._oracle_args()
+        S, I, info, d = hb["state"], hb["istate"], state.info, state.data
+        S[0:19, 0], S[19:37, 0], S[37:55, 0] = d.qpos, d.qvel, d.qacc_warmstart
+        for name, off, cnt in INFO_ROWS:
+            S[off:off + cnt, 0] = np.asarray(info[name], np.float64)
+        S[abi.S_PHASE_DT, 0], S[abi.S_GAIT_FREQ, 0] = info["phase_dt"], info["gait_freq"]
+        S[abi.S_LAST_CONTACT:abi.S_LAST_CONTACT + 4, 0] = np.asarray(info["last_contact"], np.float64)
+        I[abi.I_STEP, 0], I[abi.I_STEPS_UNTIL_CMD, 0] = int(info["step"]), int(info["steps_until_next_cmd"])
+        oracle.step(cs, ms, terrain, hb, np.asarray(action, np.float32)[None], seed=int(info["rng"][1]), nthreads=1, fp64=True)
+        return self._state(hb, info["rng"])
+
+
+TASK = {"task": "flat_terrain"}          # the task of the env built last: the stand-in mjx.step needs it to tell a box model from a plane model
+
+
+def install() -> Dict[str, Any]:
+    """-> the modules gen_golden_mjx.MjxBackend would import on a real machine"""
+    jax, jp = make_jax()
+    mujoco = types.ModuleType("mujoco")
+    mujoco.__version__ = "0.0-standin"
+    mujoco.mjtObj = types.SimpleNamespace(mjOBJ_SENSOR=0)
+    mujoco.mj_id2name = lambda m, t, i: f"sensor{i}"
+    mjx = make_mjx(TASK)
+    mujoco.mjx = mjx
+    mjx_env = types.ModuleType("mujoco_playground._src.mjx_env")
+    rconfigs = types.ModuleType("go2.configs")
+    rconfigs.default_config = lambda: _attr(configs.default_config())          # go2/configs.py:6-79 (the repo's mirror of it, pinned by tests/test_abi.py)
+    jpg = types.ModuleType("go2.joystick_pgtt")
+    jpg.Joystick = Joystick
+    return dict(jax=jax, jp=jp, mujoco=mujoco, mjx=mjx, mjx_env=mjx_env, rconfigs=rconfigs, jpg=jpg, rrand=make_randomize(TASK))

@@ -31,9 +31,11 @@ plus a TARGETED group on a hand-made terrain matrix that settles the three recor
         stale compiled rbound (go2_mjx_feetonly.xml:14-15).
 
 tests/test_mjx_pin.py consumes the file: oracle-f64 against it on CPU, the HIP kernels against it on the GPU (`-m gpu`), both
-self-skipping while tests/golden/mjx_step.npz does not exist.  The DRY RUN proves the plumbing here: a backend built on
-oracle.forward / oracle.step produces a file of the same layout (arbitrary "MuJoCo" geom ids included, so the id -> (foot, box)
-mapping of go2/base.py:87-105 is exercised) and the tests run green on it in this container.
+self-skipping while tests/golden/mjx_step.npz does not exist.  The DRY RUN proves the plumbing here: tools/fake_mjx.py supplies
+stand-ins for jax / mujoco / mjx / playground and the reference's three modules, with oracle.forward / oracle.step doing the
+arithmetic, and the SAME MjxBackend code below runs on them unchanged - every call, attribute name and shape of the recorder is
+executed (stand-in "MuJoCo" ids differ from the real model's on purpose, so the id -> (foot, box) mapping of go2/base.py:87-105
+is exercised) - and the tests run green on the file in this container.
 
 This file is a tool: nothing in the product, bench.py or __graft_entry__.py imports it.  The MJX backend below cannot be executed in
 the build container; it is written against the public API of mujoco >= 3.2 / mujoco_playground >= 0.0.4 and reads every optional field
@@ -115,7 +117,15 @@ class MjxBackend:
     its XML paths are relative: go2/go2_constants.py:21)"""
     name = "mjx"
 
-    def __init__(self, ref: str):
+    def __init__(self, ref: Optional[str], standins: Optional[Dict[str, Any]] = None):
+        """`standins`: the module set of tools/fake_mjx.install() instead of the real packages (--dry-run); everything below this constructor is the
+        same code either way"""
+        self.missing: List[str] = []
+        if standins is not None:
+            self.name = "dry-run(oracle behind stand-in jax / mujoco / mjx / go2 modules)"
+            for k, v in standins.items():
+                setattr(self, k, v)
+            return
         self.ref = os.path.abspath(ref)
         os.chdir(self.ref)
         sys.path.insert(0, self.ref)
@@ -130,7 +140,6 @@ class MjxBackend:
         import go2.joystick_pgtt as jpg
         import go2.randomize as rrand
         self.rconfigs, self.jpg, self.rrand = rconfigs, jpg, rrand
-        self.missing: List[str] = []
 
     def versions(self) -> Dict[str, str]:
         import importlib.metadata as md
@@ -224,8 +233,10 @@ class MjxBackend:
             out[k] = a if h["batched"] else np.broadcast_to(a, (n,) + a.shape).copy()
         return out
 
-    def _physics_out(self, d) -> Dict[str, np.ndarray]:
+    def _physics_out(self, d, full: bool = True) -> Dict[str, np.ndarray]:
         out = {"qpos": self._np(d.qpos), "qvel": self._np(d.qvel), "qacc_warmstart": self._np(d.qacc_warmstart)}
+        if not full:
+            return out
         for name in ("qacc", "sensordata", "actuator_force", "qfrc_bias", "qfrc_passive", "qfrc_actuator", "qfrc_constraint", "qfrc_smooth", "qacc_smooth",
                      "efc_force", "efc_D", "efc_aref", "efc_pos", "site_xpos", "site_xmat", "xpos", "xquat", "subtree_com"):
             v = self._field(d, name)
@@ -252,7 +263,7 @@ class MjxBackend:
 
     def joystick_step(self, h, action: np.ndarray) -> Dict[str, np.ndarray]:
         s1 = h["step"](h["model_v"], h["state"], self.jp.asarray(action, dtype=np.float32))
-        out = self._physics_out(s1.data)
+        out = self._physics_out(s1.data, full=False)          # the solver-level fields of a control step's LAST substep add nothing to the one-mjx.step record
         out["obs_state"], out["obs_priv"] = self._np(s1.obs["state"]), self._np(s1.obs["privileged_state"])
         out["reward"], out["done"] = self._np(s1.reward), self._np(s1.done)
         keys = list(self._config().reward_config.scales.keys())
@@ -294,199 +305,7 @@ class MjxBackend:
         return out
 
 
-# ====================================================================================================================== backend: dry run
-class OracleBackend:
-    """DRY RUN: the repo's CPU oracle (oracle.forward = one mjx.forward + Euler, oracle.step = Joystick.step, both in float64) behind the same
-    interface, with MADE-UP MuJoCo ids (the real compiled model numbers the floor 0, the robot's geoms next and the boxes from 57,
-    go2/randomize.py:24-25; the dry run uses other numbers on purpose: nothing downstream may hard-code them).  Proves the recorder, the file layout,
-    the raw-DR-field -> params conversion and the geom-id -> (foot, box) mapping; it pins NOTHING about MJX."""
-    name = "dry-run(oracle)"
-    NBODY_ROBOT0, NGEOM_BOX0 = 1, 40          # fake ids: robot bodies 1..13, boxes are bodies 20.. / geoms 40..
-    NBODY_BOX0 = 20
-    FEET_GEOM = {"FR": 31, "FL": 27, "RR": 38, "RL": 35}
-
-    def __init__(self):
-        sys.path.insert(0, ROOT)
-        from oracle import oracle
-        from phase_guided_terrain_traversal_amd import abi, configs, mjcf, randomize
-        self.oracle, self.abi, self.configs, self.mjcf, self.randomize = oracle, abi, configs, mjcf, randomize
-        self.missing: List[str] = []
-
-    def versions(self) -> Dict[str, str]:
-        return {"python": sys.version.split()[0], "numpy": np.__version__, "backend": "oracle (dry run) - NOT mjx"}
-
-    def _cfg(self):
-        return self.configs.with_overrides(self.configs.training_config(), **{"noise_config.level": 0.0})
-
-    def make_batch(self, task, terrain, n, seed, dr):
-        abi, oracle = self.abi, self.oracle
-        model = self.mjcf.load_model(task)
-        cs, ms = abi.config_struct(self._cfg()), abi.model_struct(model)
-        out = self.randomize.domain_randomize(model, n, seed=seed, terrain=terrain, enable=dr, group_variants=False)
-        hb = oracle.HostBuffers(n, with_params=True, with_variant=terrain is not None, with_box_friction=terrain is not None)
-        hb["params"][:] = out["params"]
-        if terrain is not None:
-            hb["variant"][:] = out["variant"]; hb["box_friction"][:] = out["box_friction"]
-        oracle.reset(cs, ms, terrain, hb, seed=seed, nthreads=8)
-        return dict(model=model, cs=cs, ms=ms, hb=hb, n=n, terrain=terrain, task=task, seed=seed)
-
-    def rollout(self, h, steps, seed):
-        rng = np.random.default_rng(seed)
-        for _ in range(steps):
-            a = np.tanh(rng.normal(size=(h["n"], 12)) * 0.6).astype(np.float32)
-            self.oracle.step(h["cs"], h["ms"], h["terrain"], h["hb"], a, seed=h["seed"], nthreads=8, fp64=True)
-
-    def set_states(self, h, qpos, qvel):
-        S = h["hb"]["state"]
-        S[0:19] = np.asarray(qpos, dtype=np.float32).T; S[19:37] = np.asarray(qvel, dtype=np.float32).T; S[37:55] = 0.0
-
-    def far_timer(self, h):
-        h["hb"]["istate"][self.abi.I_STEPS_UNTIL_CMD] = FAR_TIMER
-
-    def read_inputs(self, h):
-        abi = self.abi
-        S, I = h["hb"]["state"].astype(np.float64), h["hb"]["istate"]
-        row = lambda a, k: S[a:a + k].T.copy()
-        out = {"qpos": row(0, 19), "qvel": row(19, 18), "qacc_warmstart": row(37, 18)}
-        out.update(info_command=row(abi.S_CMD, 3), info_step=I[abi.I_STEP].copy(), info_steps_until_next_cmd=I[abi.I_STEPS_UNTIL_CMD].copy(),
-                   info_phase=row(abi.S_PHASE, 4), info_phase_dt=S[abi.S_PHASE_DT].copy(), info_gait_freq=S[abi.S_GAIT_FREQ].copy(),
-                   info_last_act=row(abi.S_LAST_ACT, 12), info_last_last_act=row(abi.S_LAST_LAST_ACT, 12), info_feet_air_time=row(abi.S_AIR_TIME, 4),
-                   info_last_contact=row(abi.S_LAST_CONTACT, 4) > 0.5, info_swing_peak=row(abi.S_SWING_PEAK, 4), info_H_max=row(abi.S_HMAX, 4),
-                   info_H_min=row(abi.S_HMIN, 4), info_motor_targets=row(abi.S_MOTOR_TARGETS, 12), info_qpos_error_history=row(abi.S_QERR_HIST, 24),
-                   info_qvel_history=row(abi.S_QVEL_HIST, 24))
-        return out
-
-    def read_dr(self, h):
-        """the per-env model fields in MuJoCo's own layout (what MjxBackend reads off the batched mjx.Model)"""
-        abi, n, model = self.abi, h["n"], h["model"]
-        P = h["hb"]["params"].astype(np.float64)
-        nb = self.NBODY_BOX0 + abi.MAX_BOX
-        ng = self.NGEOM_BOX0 + abi.MAX_BOX
-        body_mass = np.zeros((n, nb)); body_mass[:, 1:14] = P[abi.P_BODY_MASS:abi.P_BODY_MASS + 13].T
-        body_ipos = np.zeros((n, nb, 3)); body_ipos[:, 1:14] = np.asarray(model["body_ipos"])[None]; body_ipos[:, 1] = P[abi.P_BASE_IPOS:abi.P_BASE_IPOS + 3].T
-        qpos0 = np.repeat(np.asarray(model["qpos0"], dtype=np.float64)[None], n, 0); qpos0[:, 7:] = P[abi.P_QPOS0:abi.P_QPOS0 + 12].T
-        arm = np.zeros((n, 18)); arm[:, 6:] = P[abi.P_ARMATURE:abi.P_ARMATURE + 12].T
-        damp = np.zeros((n, 18)); damp[:, 6:] = P[abi.P_DAMPING:abi.P_DAMPING + 12].T
-        gain = np.zeros((n, 12, 10)); gain[:, :, 0] = P[abi.P_GAIN:abi.P_GAIN + 12].T
-        bias = np.zeros((n, 12, 10)); bias[:, :, :3] = np.asarray(model["act_bias"])[None]; bias[:, :, 1] = P[abi.P_BIAS1:abi.P_BIAS1 + 12].T
-        fr = np.zeros((n, ng, 3)); fr[:, 0, 0] = P[abi.P_FLOOR_FRICTION]
-        body_pos = np.zeros((n, nb, 3)); body_quat = np.zeros((n, nb, 4)); body_quat[..., 0] = 1.0; geom_size = np.zeros((n, ng, 3))
-        if h["terrain"] is not None:
-            boxes = h["terrain"][h["hb"]["variant"]].astype(np.float64)                 # [n, B, 10]
-            B = boxes.shape[1]
-            body_pos[:, self.NBODY_BOX0:self.NBODY_BOX0 + B] = boxes[..., 0:3]; body_quat[:, self.NBODY_BOX0:self.NBODY_BOX0 + B] = boxes[..., 3:7]
-            geom_size[:, self.NGEOM_BOX0:self.NGEOM_BOX0 + B] = boxes[..., 7:10]
-            fr[:, self.NGEOM_BOX0:self.NGEOM_BOX0 + abi.MAX_BOX, 0] = h["hb"]["box_friction"].T
-        return {"geom_friction": fr, "body_ipos": body_ipos, "body_mass": body_mass, "qpos0": qpos0, "dof_frictionloss": np.zeros((n, 18)), "dof_armature": arm,
-                "dof_damping": damp, "actuator_gainprm": gain, "actuator_biasprm": bias, "body_pos": body_pos, "body_quat": body_quat, "geom_size": geom_size}
-
-    def geom_ids(self, h):
-        floor = [0] + ([self.NGEOM_BOX0 + b for b in range(self.abi.MAX_BOX)] if h["terrain"] is not None else [])
-        return {"feet_geom_id": np.array([self.FEET_GEOM[f] for f in FEET]), "floor_geom_id": np.array(floor)}
-
-    def _fake_geom(self, foot_leg: int, box: int):
-        """oracle contact (foot leg FL,FR,RL,RR ; box index, -1 plane) -> (geom1, geom2) in the fake numbering (plane / box first, like MJX's pair order)"""
-        foot = self.FEET_GEOM[["FL", "FR", "RL", "RR"][foot_leg]]
-        return (0, foot) if box == -1 else (foot, self.NGEOM_BOX0 + box)
-
-    def _forward_all(self, h, ctrl):
-        abi, hb, n = self.abi, h["hb"], h["n"]
-        S = hb["state"].astype(np.float64)
-        outs = []
-        for e in range(n):
-            boxes = bf = None
-            if h["terrain"] is not None:
-                boxes = h["terrain"][hb["variant"][e]]; bf = hb["box_friction"][:boxes.shape[0], e]
-            outs.append(self.oracle.forward(h["ms"], S[0:19, e], S[19:37, e], ctrl[e], warm=S[37:55, e], boxes=boxes, box_friction=bf,
-                                            params=hb["params"][:, e], fp64=True))
-        return outs
-
-    def mjx_step(self, h, ctrl):
-        n = h["n"]
-        D = self._forward_all(h, np.asarray(ctrl, dtype=np.float64))
-        st = lambda k: np.stack([d[k] for d in D])
-        out = {"qpos": st("qpos_next"), "qvel": st("qvel_next"), "qacc_warmstart": st("qacc"), "qacc": st("qacc"), "sensordata": st("sensordata"),
-               "actuator_force": st("actuator_force"), "qfrc_bias": st("qfrc_bias"), "qfrc_passive": st("qfrc_passive"), "qfrc_actuator": st("qfrc_actuator"),
-               "qfrc_constraint": st("qfrc_constraint"), "efc_force": st("efc_force")}
-        geom = np.zeros((n, 8, 2), dtype=np.int32); dist = np.ones((n, 8)); frame = np.zeros((n, 8, 3, 3)); pos = np.zeros((n, 8, 3))
-        for e, d in enumerate(D):
-            # shuffle the slot order: MJX's own order (by geom-type pair, then top-k) is not the oracle's, and nothing may depend on it
-            order = np.random.default_rng(e).permutation(8)
-            for slot, k in enumerate(order):
-                foot, box = int(d["con_foot"][k]), int(d["con_box"][k])
-                if box == -2:                     # unused slot: MJX pads with dist > 0 and SOME geom pair; the dry run pads with (floor, a foot)
-                    geom[e, slot] = (0, self.FEET_GEOM["FR"]); dist[e, slot] = 1.0
-                    continue
-                geom[e, slot] = self._fake_geom(foot, box); dist[e, slot] = d["con_dist"][k]; frame[e, slot] = d["con_frame"][k]; pos[e, slot] = d["con_pos"][k]
-        out.update(contact_geom=geom, contact_dist=dist, contact_frame=frame, contact_pos=pos)
-        return out
-
-    def joystick_step(self, h, action):
-        abi, oracle, n = self.abi, self.oracle, h["n"]
-        hb = h["hb"]
-        h2 = oracle.HostBuffers(n, with_params=True, with_variant="variant" in hb.arrays, with_box_friction="box_friction" in hb.arrays)
-        for k, v in hb.arrays.items():
-            h2[k][...] = v
-        oracle.step(h["cs"], h["ms"], h["terrain"], h2, np.asarray(action, dtype=np.float32), seed=h["seed"], nthreads=8, fp64=True)
-        ins = self.read_inputs(dict(h, hb=h2))
-        out = {"qpos": ins["qpos"], "qvel": ins["qvel"], "qacc_warmstart": ins["qacc_warmstart"]}
-        out.update({k: v for k, v in ins.items() if k.startswith("info_")})
-        out["obs_state"], out["obs_priv"] = h2["obs_state"].astype(np.float64), h2["obs_priv"].astype(np.float64)
-        out["reward"], out["done"] = h2["reward"].astype(np.float64), h2["done"].astype(np.float64)
-        out["metrics"] = h2["metrics"].T.astype(np.float64)
-        out["metric_keys"] = np.array(abi.REWARD_KEYS + ["swing_peak"])
-        out["scan_z"] = h2["scan_z"].astype(np.float64)
-        return out
-
-    def model_constants(self, h):
-        """the repo's compiled constants under MuJoCo's names and shapes (fake ids as above) - a self-consistency dry run of the comparison code"""
-        abi, m = self.abi, h["model"]
-        nb, ng = self.NBODY_BOX0 + abi.MAX_BOX, self.NGEOM_BOX0 + abi.MAX_BOX
-        A = lambda k: np.asarray(m[k], dtype=np.float64)
-        out: Dict[str, Any] = {"opt_timestep": A("timestep"), "opt_gravity": A("gravity"), "opt_impratio": A("impratio"), "opt_tolerance": A("tolerance"),
-                               "opt_ls_tolerance": A("ls_tolerance"), "opt_iterations": np.asarray(m["iterations"]), "opt_ls_iterations": np.asarray(m["ls_iterations"]),
-                               "stat_meaninertia": A("meaninertia"), "numeric_max_contact_points": A("max_contact_points"), "numeric_max_geom_pairs": A("max_geom_pairs")}
-
-        def bodies(k, width, fill=0.0):
-            a = np.full((nb,) + ((width,) if width else ()), fill); a[1:14] = A(k); return a
-        for k, w in (("body_mass", 0), ("body_inertia", 3), ("body_ipos", 3), ("body_iquat", 4), ("body_pos", 3), ("body_quat", 4), ("body_invweight0", 2)):
-            out[k] = bodies(k, w)
-        for k in ("dof_invweight0", "dof_armature", "dof_damping", "qpos0", "key_qpos"):
-            out[k] = A(k)
-        out["dof_frictionloss"] = np.zeros(18)
-        out["jnt_range"] = np.vstack([np.zeros((1, 2)), A("jnt_range")]); out["jnt_axis"] = np.vstack([np.zeros((1, 3)), A("jnt_axis")])
-        out["jnt_solref"] = np.tile(A("jnt_solref"), (13, 1)); out["jnt_solimp"] = np.tile(A("jnt_solimp"), (13, 1))
-        gain = np.zeros((12, 10)); gain[:, 0] = A("act_gain"); bias = np.zeros((12, 10)); bias[:, :3] = A("act_bias")
-        out["actuator_gainprm"], out["actuator_biasprm"] = gain, bias
-        out["actuator_ctrlrange"], out["actuator_forcerange"] = A("act_ctrlrange"), A("act_forcerange")
-        out["actuator_trnid"] = np.stack([np.asarray(m["act_dof"]) - 6 + 1, np.full(12, -1)], axis=1)          # joint ids: free joint 0, hinges 1..12
-        for k, w in (("geom_friction", 3), ("geom_solref", 2), ("geom_solimp", 5), ("geom_margin", 0), ("geom_gap", 0), ("geom_solmix", 0), ("geom_condim", 0),
-                     ("geom_size", 3), ("geom_pos", 3), ("geom_rbound", 0), ("geom_bodyid", 0)):
-            out[k] = np.zeros((ng,) + ((w,) if w else ()))
-        ids = self.geom_ids(h)
-        sets = [("floor", [0])] + [("foot", [int(g)]) for g in ids["feet_geom_id"]] + [("box", list(range(self.NGEOM_BOX0, ng)))]
-        for kind, gl in sets:
-            for g in gl:
-                for k in ("friction", "solref", "solimp", "margin", "gap", "solmix", "condim"):
-                    out["geom_" + k][g] = A(f"{kind}_{k}")
-        for i, f in enumerate(FEET):
-            leg = ["FL", "FR", "RL", "RR"].index(f)
-            g = int(ids["feet_geom_id"][i])
-            out["geom_size"][g, 0] = A("foot_radius")[leg]; out["geom_pos"][g] = A("foot_geom_pos")[leg]; out["geom_bodyid"][g] = 1 + 3 * leg + 2 + 1
-            out["geom_rbound"][g] = A("foot_radius")[leg]
-        out["geom_rbound"][self.NGEOM_BOX0:ng] = A("box_rbound")
-        out["geom_bodyid"][self.NGEOM_BOX0:ng] = np.arange(self.NBODY_BOX0, nb)
-        site_pos = np.zeros((5, 3)); site_pos[0] = A("imu_pos")
-        feet_site = []
-        for i, f in enumerate(FEET):                                  # sites [imu, FL, FR, RL, RR] like the XML; FEET order FR, FL, RR, RL
-            leg = ["FL", "FR", "RL", "RR"].index(f)
-            site_pos[1 + leg] = A("foot_site_pos")[leg]; feet_site.append(1 + leg)
-        out["site_pos"], out["feet_site_id"], out["imu_site_id"] = site_pos, np.array(feet_site), np.asarray(0)
-        out["nbody"], out["ngeom"] = np.asarray(nb), np.asarray(ng)
-        return out
-
-
-# ====================================================================================================================== recorder (shared by both backends)
+# ====================================================================================================================== recorder
 def record_group(be, name: str, task: str, terrain: Optional[np.ndarray], n: int, seed: int, dr: bool, roll: int, cases=None) -> Dict[str, np.ndarray]:
     """one group of the fixture: n envs brought to a state (a roll-out of `roll` steps, or the crafted `cases`), then from THAT state one mjx.step
     and one Joystick.step, inputs and outputs recorded.  Keys: '<name>/in_*', '<name>/dr_*', '<name>/mjx_*', '<name>/step_*'."""
@@ -525,7 +344,7 @@ def main(argv=None) -> int:
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("--ref", default="/root/reference", help="checkout of NtagkasAlex/phase_guided_terrain_traversal (imported, never copied)")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "mjx_step.npz"))
-    ap.add_argument("--dry-run", action="store_true", help="the repo's CPU oracle stands in for mjx (plumbing check, pins nothing)")
+    ap.add_argument("--dry-run", action="store_true", help="stand-in modules backed by the repo's CPU oracle instead of jax / mujoco / mjx / the reference (tools/fake_mjx.py; plumbing check, pins nothing)")
     ap.add_argument("--envs-flat", type=int, default=96)
     ap.add_argument("--envs-level4", type=int, default=128)
     ap.add_argument("--roll", type=int, default=30, help="control steps of random actions before the recorded state")
@@ -533,7 +352,12 @@ def main(argv=None) -> int:
     a = ap.parse_args(argv)
     if a.dry_run and os.path.abspath(a.out) == os.path.join(ROOT, "tests", "golden", "mjx_step.npz"):
         raise SystemExit("--dry-run must not write tests/golden/mjx_step.npz (that name is reserved for vectors of the real MJX): pass --out")
-    be = OracleBackend() if a.dry_run else MjxBackend(a.ref)
+    if a.dry_run:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import fake_mjx
+        be = MjxBackend(None, standins=fake_mjx.install())
+    else:
+        be = MjxBackend(a.ref)
     lvl = a.level4 or (os.path.join(ROOT, "phase_guided_terrain_traversal_amd", "assets", "terrains", "level4.npy") if a.dry_run else os.path.join(a.ref, "terrains", "level4.npy"))
     level4 = np.load(lvl).astype(np.float32)
     data: Dict[str, np.ndarray] = {}
