@@ -381,6 +381,44 @@ def test_targeted_check_detects_a_backend_that_flips_the_contact_frame(tmp_path)
         test_targeted_cases_settle_the_recorded_model_questions(Pin(out))
 
 
+def test_recorder_uses_names_the_reference_source_really_has():
+    """the MJX backend of tools/gen_golden_mjx.py was written against the reference's SOURCE and has never met the real packages: every attribute, key and
+    signature it relies on is looked up in that source here (this container only - the GPU box has no /root/reference: skip)"""
+    import ast
+    import re
+    ref = os.environ.get("PGTT_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "go2")):
+        pytest.skip("reference checkout not present")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_golden_mjx as G
+    base = open(os.path.join(ref, "go2", "base.py")).read()
+    joy = open(os.path.join(ref, "go2", "joystick_pgtt.py")).read()
+    rnd = open(os.path.join(ref, "go2", "randomize.py")).read()
+    cfg = open(os.path.join(ref, "go2", "configs.py")).read()
+    for attr in ("_feet_geom_id", "_floor_geom_id", "_imu_site_id", "_feet_site_id", "_mjx_model", "_mj_model"):
+        assert re.search(r"self\.%s\s*=" % attr, base), attr                                   # what MjxBackend reads off the env object
+    assert re.search(r"def mjx_model\(self\)", base) and re.search(r"def mj_model\(self\)", base)
+    # Joystick(task=..., config=...), reset(rng), step(state, action)
+    tree = ast.parse(joy)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "Joystick")
+    fn = {n.name: [a.arg for a in n.args.args] for n in cls.body if isinstance(n, ast.FunctionDef)}
+    assert fn["__init__"][:3] == ["self", "task", "config"] and fn["reset"] == ["self", "rng"] and fn["step"] == ["self", "state", "action"]
+    # every info key the recorder reads is a key of the dict literal Joystick.reset builds; the observation keys; the metric names
+    reset_src = ast.get_source_segment(joy, next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "reset"))
+    for k in G.INFO_KEYS + ["rng", "heightscan"]:
+        assert re.search(r'"%s"\s*:' % k, reset_src), k
+    assert '"state"' in joy and '"privileged_state"' in joy and 'metrics[f"reward/{k}"]' in joy and 'metrics["swing_peak"]' in joy
+    assert "self._weights" in reset_src                                  # the attribute Joystick.step needs from a previous reset (why make_batch resets the base env once)
+    # the randomization_fn: signature, returned pair, and exactly the per-env fields the recorder records
+    assert re.search(r"def domain_randomize\(model[^,]*,\s*rng[^,]*,\s*terrain_matrix", rnd) and "return model, in_axes" in rnd
+    marked = set(re.findall(r'"(\w+)"\s*:\s*0', rnd))
+    assert marked == set(G.DR_FIELDS), (marked, G.DR_FIELDS)
+    # the config fields the recorder overrides exist (training/train.py:127-129 + the noise level)
+    for k in ("command_config", "u_max", "u_min", "gait_freq", "noise_config", "level", "reward_config", "scales", "action_scale"):
+        assert re.search(r"\b%s\b" % k, cfg), k
+    assert re.search(r"action_scale\s*=\s*0\.5", cfg)                       # motor_targets = default_pose + 0.5 * action in record_group
+
+
 def test_generator_refuses_to_write_a_dry_run_under_the_real_name():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_golden_mjx.py"), "--dry-run"], capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "reserved" in p.stderr and not os.path.exists(REAL)
