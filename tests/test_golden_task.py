@@ -86,18 +86,21 @@ def _run_case(g, i, ms, cs, fp64, method="pgtt"):
     return hb
 
 
+@pytest.mark.parametrize("source", ["synthetic", "rollout"])
 @pytest.mark.parametrize("method", ["pgtt", "baseline"])
 @pytest.mark.parametrize("fp64", [True, False])
-def test_task_step_against_reference(golden_dir, ms, fp64, method):
+def test_task_step_against_reference(golden_dir, ms, fp64, method, source):
     """go2/joystick_pgtt.py (method pgtt) and go2/joystick.py (method baseline) executed end to end by the reference's
-    own Python on fake physics outputs (tools/gen_golden.py) vs the oracle's task layer"""
-    g = np.load(os.path.join(golden_dir, "task_step.npz" if method == "pgtt" else "task_step_baseline.npz"))
+    own Python (tools/gen_golden.py) vs the oracle's task layer - on 14 synthetic states per task (`synthetic`) and CLOSED LOOP along roll-outs whose
+    physics outputs come from the oracle (`rollout`: 240 / 120 consecutive steps of 6 / 4 robots; the reference carries its own `info` from step to step)"""
+    from conftest import GoldenCases
+    g = GoldenCases(os.path.join(golden_dir, ("task_step" if source == "synthetic" else "task_step_rollout") + ("" if method == "pgtt" else "_baseline") + ".npz"))
     cs = abi.config_struct(configs.training_config(method))
     od, pd = abi.obs_dims(method)
     assert g["c0_obs"].shape == (od,) and g["c0_priv"].shape == (pd,)
     # buffers are fp32 even for the f64 build, so compare at fp32 resolution of the magnitudes involved
     tol = 2e-5 if fp64 else 2e-4
-    for i in range(int(g["ncases"])):
+    for i in range(g.ncases):
         hb = _run_case(g, i, ms, cs, fp64, method)
         k = lambda n: g[f"c{i}_{n}"]
         S, I = hb["state"][:, 0], hb["istate"][:, 0]
