@@ -54,10 +54,6 @@ class Struct:
         return self.replace(**d)
 
 
-def _is_leaf(x):
-    return not isinstance(x, (Struct, dict))
-
-
 def tree_slice(x, ax, i):
     """element i of the leaves whose in_axes entry is 0; `ax` is None / 0 for the whole subtree or a tree of the same shape"""
     if isinstance(x, Struct):
@@ -115,7 +111,6 @@ def make_jax():
     rnd.PRNGKey = lambda seed: np.array([0, int(seed)], dtype=np.uint32)
     rnd.split = lambda key, n=2: np.stack([np.array([int(key[1]) % 65521, (int(key[1]) * 1000003 + 7919 * (i + 1)) % (2 ** 31)], dtype=np.uint32) for i in range(n)])
     jax.random = rnd
-    jax.tree_util = types.SimpleNamespace(tree_map=lambda f, t: type(t)(**{k: f(v) for k, v in t.__dict__.items()}))
     return jax, np            # jax.numpy: numpy has every function the recorder calls (asarray, broadcast_to, zeros_like, full_like, stack)
 
 
@@ -252,7 +247,7 @@ def make_mjx(task_ref):
                             actuator_force=d["actuator_force"], qfrc_bias=d["qfrc_bias"], qfrc_passive=d["qfrc_passive"], qfrc_actuator=d["qfrc_actuator"],
                             qfrc_constraint=d["qfrc_constraint"], qfrc_smooth=d["qfrc_smooth"], qacc_smooth=d["qacc_smooth"], efc_force=d["efc_force"],
                             efc_D=d["efc_D"], efc_aref=d["efc_aref"], efc_pos=d["efc_pos"], xpos=d["xpos"], xquat=d["xquat"], subtree_com=d["com"][None],
-                            site_xpos=np.vstack([np.zeros((1, 3)), d["site_foot"][[1, 0, 3, 2]]]), site_xmat=np.stack([d["site_imu_mat"]] + [np.eye(3)] * 4),
+                            site_xpos=np.vstack([np.zeros((1, 3)), d["site_foot"]]), site_xmat=np.stack([d["site_imu_mat"]] + [np.eye(3)] * 4),      # recorded, not compared
                             contact=_contact_struct(d, seed))
     mjx.step = step
     mjx.forward = lambda model, data: data          # derived quantities are recomputed by every step
