@@ -145,7 +145,6 @@ def active(d):
 
 
 def oracle_forward(pin, group, mi, model, e):
-    S = pin.state_rows(group)[0].astype(np.float64)
     boxes = bf = None
     if mi["terrain"] is not None:
         boxes = mi["terrain"][mi["variant"][e]]; bf = mi["box_friction"][:boxes.shape[0], e]
