@@ -597,7 +597,7 @@ def test_tilted_box_many_box_pass_parity(layout):
         assert (eg["qpos"][well] > 1e-4).sum() <= max(1, 0.01 * well.sum()), (k, eg["qpos"][well].max())
         assert (eg["scan"][well] > 1e-5).sum() <= 1          # a ray next to a slab's side face may land on the other side of it (a step of the scan, not an error)
     print(layout, "env-steps", total, "took the many-box pass", flagged, "| in W", well_total, ": ACTIVE-set mismatches", mism, "| flag mismatches", flag_mism, "| oracle box contacts", deep_pairs)
-    assert flagged > 0.5 * total and deep_pairs > 3 * total and well_total > 0.25 * total
+    assert flagged > 0.5 * total and deep_pairs > 2.5 * total and well_total > 0.25 * total          # measured: 73 % flagged, 3.35 box contacts per env-step, W = 49 %
     assert mism <= 1 and flag_mism <= 1
     env.close()
 
