@@ -362,6 +362,34 @@ def test_library_refuses_without_bind():
     L.pgtt_destroy(h)
 
 
+def nearest_boxes(terrain, B):
+    """the B boxes of every variant whose centres lie nearest to the spawn area: a terrain table with FEWER than 100 boxes per variant"""
+    out = np.zeros((terrain.shape[0], B, 10), np.float32)
+    for v in range(terrain.shape[0]):
+        order = np.argsort(np.hypot(terrain[v, :, 0], terrain[v, :, 1]), kind="stable")[:B]
+        out[v] = terrain[v, np.sort(order)]
+    return out
+
+
+@pytest.mark.parametrize("B", [37, 6, 1])
+def test_fewer_than_100_boxes_parity(layout, B):
+    """pgtt_set_terrain accepts any B <= 100 (the reference's scene always carries 100 placeholders, terrain_scene_mjx.xml:20-21): B = 37 leaves every
+    sub-lane split of the 100-box loops ragged and ends the table of the LAST variant exactly at its last record (the quad layout's rank pass used to
+    prefetch one record further: ADVICE r04); B = 6 is the largest count for which MJX's broad phase does not cut (4 x 6 = 24 <= max_geom_pairs = 25: every
+    pair goes to the narrow phase); B = 1 is a single slab"""
+    lvl = np.load(os.path.join(ASSETS, "terrains", "level4.npy"))
+    terrain = nearest_boxes(lvl, B)
+    if B == 1:
+        terrain[:, 0] = [0.0, 0.0, 0.03, 1, 0, 0, 0, 2.0, 2.0, 0.03]
+        terrain[1::2, 0, 7] = 0.6                      # every other variant: a narrower slab, so feet also meet its edges and the plane
+    assert terrain.shape[1] == B
+    st = run_parity("stairs", 128, terrain, steps=20, w_floor=0.6)
+    assert st["box_contacts"] > (300 if B > 1 else 1500)
+    # the same with domain randomisation (per-box friction rows are [100][N] whatever B is) and AutoReset
+    if B == 37:
+        run_parity("stairs", 96, terrain, steps=16, dr=True, autoreset=True, w_floor=0.6)
+
+
 def test_terrain_table_beyond_32_bit_offsets_is_refused():
     """the quad / oct kernels address the terrain table and the cell grid through 32-bit byte offsets from their bases: a table that does not fit is a
     PGTT_E_ARG of pgtt_set_terrain (checked before the table is read), not a wrapped offset"""
@@ -562,6 +590,19 @@ def test_tilted_box_contact_parity(layout):
     st = run_parity("stairs", 192, terrain, steps=30, w_floor=0.55, cap_scale=2.0, med_tol=4e-6)
     assert st["box_contacts"] > 1500 and st["box_contacts"] > 0.25 * st["active_contacts"]
     assert st["well_set_mismatch"] <= 2 and st["well_flag_mismatch"] <= 1
+
+
+def test_tilted_boxes_with_dr_autoreset_and_the_baseline_task():
+    """the ramps once more with everything else switched on: full domain randomisation (per-box friction on tilted faces), AutoReset, and the baseline
+    task's observation layout; then the two-kernel observe form on the same terrain"""
+    terrain = ramp_terrain()
+    run_parity("stairs", 128, terrain, steps=24, dr=True, autoreset=True, w_floor=0.55, cap_scale=2.0, med_tol=4e-6)
+    run_parity("stairs", 96, terrain, steps=16, autoreset=True, method="baseline", w_floor=0.55, cap_scale=2.0, med_tol=4e-6)
+    EXEC["observe_form"] = "split"
+    try:
+        run_parity("stairs", 96, terrain, steps=16, autoreset=True, w_floor=0.55, cap_scale=2.0, med_tol=4e-6)
+    finally:
+        EXEC["observe_form"] = None
 
 
 def test_tilted_box_many_box_pass_parity(layout):
