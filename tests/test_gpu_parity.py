@@ -241,6 +241,13 @@ def test_flat_parity(layout):
     assert st["active_contacts"] > 1000
 
 
+def test_flat_dr_parity(layout):
+    """the flat task WITH domain randomisation (go2/randomize_simple.py:24-138: floor friction U(0.4, 1), masses, armature, damping, gains, qpos0 per env;
+    no boxes): the DR-without-terrain kernels of every layout, step and reset's forward pass, AutoReset on"""
+    st = run_parity("flat_terrain", 192, None, steps=30, dr=True, autoreset=True, w_floor=0.65)          # measured W = 72.7 %: robots with randomised gains land harder
+    assert st["active_contacts"] > 3000 and st["box_contacts"] == 0
+
+
 @pytest.fixture(params=["quad", "oct", "hex"])
 def layout(request):
     """the three lane layouts of physics_kernel (pgtt_physics_quad.hip.h): 16, 8 or 4 envs per wave"""
