@@ -187,6 +187,22 @@ int pgtt_create(const PgttConfig* cfg, const PgttModel* model, int device, int n
   if (cfg->lane_layout != PGTT_LAYOUT_AUTO && cfg->lane_layout != PGTT_LAYOUT_QUAD && cfg->lane_layout != PGTT_LAYOUT_OCT && cfg->lane_layout != PGTT_LAYOUT_HEX)
     return fail(PGTT_E_ARG, "pgtt_create: lane_layout must be PGTT_LAYOUT_AUTO, _QUAD, _OCT or _HEX");
   if (cfg->observe_form != PGTT_OBSERVE_FUSED && cfg->observe_form != PGTT_OBSERVE_SPLIT) return fail(PGTT_E_ARG, "pgtt_create: unknown observe_form");
+  // values the kernels have as compile-time shapes, not as run-time parameters: anything else is refused here rather than computed wrongly
+  if (cfg->history_len != 2) return fail(PGTT_E_ARG, "pgtt_create: history_len must be 2 (the history rows hold two samples of 12 joints, go2/configs.py)");
+  if (cfg->history_update_steps < 1) return fail(PGTT_E_ARG, "pgtt_create: history_update_steps must be >= 1");
+  if (cfg->episode_length < 1) return fail(PGTT_E_ARG, "pgtt_create: episode_length must be >= 1");
+  if (!(cfg->sim_dt > 0.f) || !(cfg->ctrl_dt > 0.f) || cfg->n_substeps != (int)std::lround(cfg->ctrl_dt / cfg->sim_dt))
+    return fail(PGTT_E_ARG, "pgtt_create: n_substeps must equal round(ctrl_dt / sim_dt) (mjx_env.MjxEnv.n_substeps)");
+  if (std::fabs(model->timestep - cfg->sim_dt) > 1e-9f) return fail(PGTT_E_ARG, "pgtt_create: model.timestep must equal config.sim_dt (go2/base.py:55)");
+  if (model->max_contact_points < 1 || model->max_contact_points > 4)
+    return fail(PGTT_E_ARG, "pgtt_create: max_contact_points must be 1 .. 4 (a foot holds at most four box contacts in the kernels; the reference uses 4)");
+  if (model->iterations < 1 || model->iterations > 64 || model->ls_iterations < 1 || model->ls_iterations > 64) return fail(PGTT_E_ARG, "pgtt_create: solver iteration counts out of range");
+  {
+    // mixed condim = max of the pair (mjx collision_driver): the constraint rows of the kernels are the 4-row pyramid of condim 3
+    const int cf = model->foot_condim > model->floor_condim ? model->foot_condim : model->floor_condim;
+    const int cb = model->foot_condim > model->box_condim ? model->foot_condim : model->box_condim;
+    if (cf != 3 || cb != 3) return fail(PGTT_E_ARG, "pgtt_create: foot-floor and foot-box contacts must mix to condim 3 (pyramidal, 4 rows per contact)");
+  }
   static const int expect_dof[12] = {9, 10, 11, 6, 7, 8, 15, 16, 17, 12, 13, 14};
   for (int a = 0; a < 12; a++)
     if (model->act_dof[a] != expect_dof[a]) return fail(PGTT_E_ARG, "pgtt_create: actuators must be declared FR,FL,RR,RL on joints FL,FR,RL,RR");

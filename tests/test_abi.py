@@ -65,6 +65,36 @@ def test_no_cpu_fallback_without_gpu():
         Joystick("flat_terrain", num_envs=8, device="cpu")
 
 
+def test_create_refuses_what_the_kernels_cannot_compute():
+    """argument checks run before the device is touched: values the kernels hold as compile-time shapes (two history samples, <= 4 box contacts per foot,
+    the 4-row pyramid of condim 3) or need consistent (n_substeps, timestep) are a PGTT_E_ARG, never a silently different simulation"""
+    if not os.path.exists(native.LIB_PATH):
+        pytest.skip("libpgtt.so not built")
+    L = native.lib()
+    base_m = mjcf.load_model("stairs")
+    h = C.c_void_p()
+
+    def rc(cfg_over=None, model_over=None, n=64):
+        c = abi.config_struct(dict(configs.training_config(), **(cfg_over or {})))
+        if cfg_over and "n_substeps" in cfg_over:
+            c.n_substeps = cfg_over["n_substeps"]
+        m = abi.model_struct(dict(base_m, **(model_over or {})))
+        return L.pgtt_create(C.byref(c), C.byref(m), 0, n, C.byref(h)), L.pgtt_last_error()
+    for over, word in (({"history_len": 3}, b"history_len"), ({"history_update_steps": 0}, b"history_update_steps"), ({"episode_length": 0}, b"episode_length"),
+                       ({"n_substeps": 3}, b"n_substeps"), ({"sim_dt": 0.004}, b"timestep")):
+        r, msg = rc(cfg_over=over)
+        assert r == -1 and word in msg, (over, r, msg)
+    for over, word in (({"max_contact_points": 8}, b"max_contact_points"), ({"max_contact_points": -1}, b"max_contact_points"), ({"timestep": 0.002}, b"timestep"),
+                       ({"floor_condim": 1, "foot_condim": 1}, b"condim"), ({"box_condim": 4}, b"condim"), ({"iterations": 0}, b"iteration")):
+        r, msg = rc(model_over=over)
+        assert r == -1 and word in msg, (over, r, msg)
+    assert rc(n=0)[0] == -1 and rc(n=(1 << 22) + 1)[0] == -1
+    r, msg = rc()                                           # the shipped values pass the checks (and then meet the device, or its absence)
+    assert r in (0, -3, -4), (r, msg)
+    if r == 0:
+        L.pgtt_destroy(h)
+
+
 def test_execution_options_come_through_the_abi_not_the_environment():
     """lane layout / observe form / test hooks are PgttConfig fields; the library reads no environment variable"""
     cfg = dict(configs.training_config(), lane_layout="oct", observe_form="split", test_hooks=True)

@@ -422,6 +422,25 @@ def test_short_episodes_autoreset_parity(layout):
     assert st["active_contacts"] > 1000
 
 
+@pytest.mark.parametrize("method", ["pgtt", "baseline"])
+def test_config_values_are_read_not_assumed(method):
+    """every scalar of go2/configs.py:6-79 that the step consumes is a run-time value of PgttConfig: with ALL of them moved off the reference's defaults
+    (all 21 reward scales non-zero - several are 0.0 in the shipped config, so their terms would otherwise never show -, the tracking / phase sigmas, swing
+    height and foot distance, command ranges and probabilities, gait-frequency range, the scan pitch and ray height, every noise scale, action scale, soft
+    limit factor, history period, episode length) the kernels still agree with the oracle, which reads the same struct"""
+    rng = np.random.default_rng(5)
+    over = {"reward_config.scales." + k: float(np.sign(v if v != 0 else rng.choice([-1.0, 1.0])) * rng.uniform(0.2, 1.5) * (abs(v) if v != 0 else 0.3))
+            for k, v in configs.default_config()["reward_config"]["scales"].items()}
+    over.update({"reward_config.tracking_sigma": 0.31, "reward_config.swing_height": -0.17, "reward_config.base_feet_distance": -0.27, "reward_config.phase_sigma": 0.08,
+                 "command_config.u_max": [0.9, 0.5, 0.8], "command_config.u_min": [-0.4, -0.6, -1.1], "command_config.b": [0.7, 0.4, 0.6], "gait_freq": [1.5, 2.5],
+                 "scan_dist_x": 0.08, "scan_dist_y": 0.12, "scan_z_offset": 0.45, "action_scale": 0.35, "soft_joint_pos_limit_factor": 0.9, "history_update_steps": 3,
+                 "episode_length": 11})
+    over.update({"noise_config.scales." + k: v for k, v in dict(joint_pos=0.05, joint_vel=1.0, gyro=0.3, gravity=0.08, linvel=0.2, heightscan=0.02).items()})
+    terrain = np.load(os.path.join(ASSETS, "terrains", "level4.npy"))
+    st = run_parity("stairs", 128, terrain, steps=30, autoreset=True, method=method, cfg_over=over)
+    assert st["box_contacts"] > 500
+
+
 def test_terrain_table_beyond_32_bit_offsets_is_refused():
     """the quad / oct kernels address the terrain table and the cell grid through 32-bit byte offsets from their bases: a table that does not fit is a
     PGTT_E_ARG of pgtt_set_terrain (checked before the table is read), not a wrapped offset"""
