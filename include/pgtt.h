@@ -104,6 +104,8 @@ typedef struct PgttModel {
   float foot_friction[3], foot_solref[2], foot_solimp[5], foot_margin, foot_gap, foot_solmix;
   float floor_friction[3], floor_solref[2], floor_solimp[5], floor_margin, floor_gap, floor_solmix;
   float box_friction[3], box_solref[2], box_solimp[5], box_margin, box_gap, box_solmix;
+  /* foot-box pairs: max(foot_margin, box_margin) - max(foot_gap, box_gap) must be <= 0 (pgtt_create refuses more: only penetrating box pairs become
+   * constraint rows; the reference has -0.001 / 0).  The plane contact takes any margin. */
   float box_rbound;                   /* stale compiled rbound of the 1x1x1 placeholder = sqrt(3) */
   int32_t foot_condim, floor_condim, box_condim;
   /* options */

@@ -203,6 +203,13 @@ int pgtt_create(const PgttConfig* cfg, const PgttModel* model, int device, int n
     const int cb = model->foot_condim > model->box_condim ? model->foot_condim : model->box_condim;
     if (cf != 3 || cb != 3) return fail(PGTT_E_ARG, "pgtt_create: foot-floor and foot-box contacts must mix to condim 3 (pyramidal, 4 rows per contact)");
   }
+  {
+    // box contacts: the collision stage keeps PENETRATING (foot, box) pairs only, which is every pair MJX can activate as long as the mixed margin
+    // max(margins) - max(gaps) of the pair is <= 0 (the reference: foot margin -0.001, box margin 0).  The plane contact has no such limit.
+    const float mg = model->foot_margin > model->box_margin ? model->foot_margin : model->box_margin;
+    const float gp = model->foot_gap > model->box_gap ? model->foot_gap : model->box_gap;
+    if (mg - gp > 0.f) return fail(PGTT_E_ARG, "pgtt_create: foot-box contacts need max(foot_margin, box_margin) - max(foot_gap, box_gap) <= 0 (rows of non-penetrating box pairs are not formed)");
+  }
   static const int expect_dof[12] = {9, 10, 11, 6, 7, 8, 15, 16, 17, 12, 13, 14};
   for (int a = 0; a < 12; a++)
     if (model->act_dof[a] != expect_dof[a]) return fail(PGTT_E_ARG, "pgtt_create: actuators must be declared FR,FL,RR,RL on joints FL,FR,RL,RR");

@@ -25,18 +25,23 @@ class PgttError(RuntimeError):
 
 def source_sha256() -> str:
     """SHA-256 over the sources physics_kernel is built from - what the translation unit csrc/pgtt_physics_inst.hip includes, plus the Makefile
-    that holds its flags (names and contents, sorted): tools/collect_profiles.py stores it next to the rocprofv3 counters of that kernel,
-    bench.py compares it before quoting them."""
+    that holds its flags - with comments and white space removed (a comment edit does not change the kernel): tools/collect_profiles.py stores it next to
+    the rocprofv3 counters of that kernel, bench.py compares it before quoting them."""
     import hashlib
+    import re
     h = hashlib.sha256()
     root = os.path.dirname(_HERE)
     files = sorted([os.path.join(_HERE, "csrc", f) for f in ("pgtt_physics_inst.hip", "pgtt_physics.hip.h", "pgtt_physics_quad.hip.h", "pgtt_kernels.hip.h", "Makefile")]
                    + [os.path.join(root, "include", "pgtt.h")])
     for f in files:
-        h.update(os.path.basename(f).encode() + b"\0")
-        with open(f, "rb") as fh:
-            h.update(fh.read())
-        h.update(b"\0")
+        with open(f, "r") as fh:
+            text = fh.read()
+        if f.endswith("Makefile"):
+            text = "\n".join(ln for ln in text.splitlines() if not ln.lstrip().startswith("#"))
+        else:
+            text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+            text = re.sub(r"//[^\n]*", " ", text)
+        h.update(os.path.basename(f).encode() + b"\0" + " ".join(text.split()).encode() + b"\0")
     return h.hexdigest()
 
 

@@ -85,7 +85,7 @@ def test_create_refuses_what_the_kernels_cannot_compute():
         r, msg = rc(cfg_over=over)
         assert r == -1 and word in msg, (over, r, msg)
     for over, word in (({"max_contact_points": 8}, b"max_contact_points"), ({"max_contact_points": -1}, b"max_contact_points"), ({"timestep": 0.002}, b"timestep"),
-                       ({"floor_condim": 1, "foot_condim": 1}, b"condim"), ({"box_condim": 4}, b"condim"), ({"iterations": 0}, b"iteration")):
+                       ({"box_margin": 0.002}, b"margin"), ({"foot_margin": 0.001, "foot_gap": 0.0005}, b"margin"), ({"floor_condim": 1, "foot_condim": 1}, b"condim"), ({"box_condim": 4}, b"condim"), ({"iterations": 0}, b"iteration")):
         r, msg = rc(model_over=over)
         assert r == -1 and word in msg, (over, r, msg)
     assert rc(n=0)[0] == -1 and rc(n=(1 << 22) + 1)[0] == -1

@@ -21,13 +21,14 @@ ASSETS = os.path.join(os.path.dirname(mjcf.__file__), "assets")
 EXEC = {"layout": None, "observe_form": None}
 
 
-def make_pair(task, n, terrain=None, noise=1.0, autoreset=False, dr=False, method="pgtt", ctrl_dt=None, product_variants=False, cfg_over=None, no_variant_buffer=False):
+def make_pair(task, n, terrain=None, noise=1.0, autoreset=False, dr=False, method="pgtt", ctrl_dt=None, product_variants=False, cfg_over=None, no_variant_buffer=False,
+              model=None):
     from phase_guided_terrain_traversal_amd.env import Joystick
     cfg = configs.with_overrides(configs.training_config(method), **{"noise_config.level": noise}, **(cfg_over or {}))
     if ctrl_dt is not None:
         cfg["ctrl_dt"] = ctrl_dt          # ctrl_dt = sim_dt: one control step = ONE mjx.step (per-substep parity)
-    model = mjcf.load_model(task)
-    kw = {}
+    model = mjcf.load_model(task) if model is None else model
+    kw = {"model": model}
     variant = params = bf = None
     if terrain is not None and not no_variant_buffer:
         variant = np.random.default_rng(2).integers(0, terrain.shape[0], n).astype(np.int32)
@@ -106,7 +107,7 @@ P90_FLOOR = dict(qpos=1.2e-7, qvel=5e-6, obs=2e-6, frame=3e-6)        # one roun
 
 
 def run_parity(task, n, terrain, steps, dr=False, autoreset=False, noise=1.0, method="pgtt", ctrl_dt=None, w_floor=None, cap_scale=1.0, med_tol=2e-6,
-               product_variants=False, cfg_over=None, no_variant_buffer=False):
+               product_variants=False, cfg_over=None, no_variant_buffer=False, model=None):
     """One control step (4 x mjx.step; ONE mjx.step with ctrl_dt = sim_dt) from an IDENTICAL state, repeated `steps` times along
     a GPU rollout (the oracle is re-synchronised from the GPU state before every step).
 
@@ -121,7 +122,7 @@ def run_parity(task, n, terrain, steps, dr=False, autoreset=False, noise=1.0, me
     """
     nsub = 4 if ctrl_dt is None else int(round(ctrl_dt / 0.005))
     env, hb, cs, ms = make_pair(task, n, terrain, noise=noise, dr=dr, autoreset=autoreset, method=method, ctrl_dt=ctrl_dt, product_variants=product_variants,
-                                cfg_over=cfg_over, no_variant_buffer=no_variant_buffer)
+                                cfg_over=cfg_over, no_variant_buffer=no_variant_buffer, model=model)
     h64 = oracle.HostBuffers(n, with_params=dr, with_variant="variant" in hb.arrays, with_box_friction="box_friction" in hb.arrays, method=method)
     for k in ("params", "variant", "box_friction"):
         if k in hb.arrays:
@@ -439,6 +440,53 @@ def test_config_values_are_read_not_assumed(method):
     terrain = np.load(os.path.join(ASSETS, "terrains", "level4.npy"))
     st = run_parity("stairs", 128, terrain, steps=30, autoreset=True, method=method, cfg_over=over)
     assert st["box_contacts"] > 500
+
+
+def perturbed_model(task, axes=False, seed=9):
+    """PgttModel with every numeric field moved off the Go2's values (what a different MJCF of the same topology would compile to): link offsets, inertial
+    frames, masses, inertias, joint ranges (narrow: limit rows become active), joint and geom solver parameters, armature, damping, actuator gains / bias /
+    ranges (tight force range: clipping becomes active), foot geometry, imu and foot sites, frictions, margins, a tilted gravity, impratio, solver tolerances
+    and iteration counts, the collision cuts (max_geom_pairs 17, max_contact_points 3), another keyframe"""
+    m = {k: (np.array(v, dtype=np.float64, copy=True) if isinstance(v, (list, np.ndarray)) else v) for k, v in mjcf.load_model(task).items()}
+    r = np.random.default_rng(seed)
+    sc = lambda a, rel: np.asarray(a, np.float64) * (1 + r.uniform(-rel, rel, np.shape(a)))
+    m["body_pos"] = m["body_pos"] + r.uniform(-0.01, 0.01, (13, 3)); m["body_ipos"] = m["body_ipos"] + r.uniform(-0.005, 0.005, (13, 3))
+    q = m["body_iquat"] + r.normal(size=(13, 4)) * 0.05; m["body_iquat"] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    m["body_mass"] = sc(m["body_mass"], 0.15); m["body_inertia"] = sc(m["body_inertia"], 0.15); m["body_invweight0"] = sc(m["body_invweight0"], 0.1)
+    m["dof_invweight0"] = sc(m["dof_invweight0"], 0.1); m["meaninertia"] = float(m["meaninertia"]) * 1.1
+    jr = np.asarray(m["jnt_range"], np.float64); mid, half = jr.mean(1), 0.5 * (jr[:, 1] - jr[:, 0])
+    m["jnt_range"] = np.stack([mid - 0.8 * half, mid + 0.8 * half], 1)
+    m["jnt_solref"] = np.array([0.03, 0.9]); m["jnt_solimp"] = np.array([0.85, 0.97, 0.002, 0.5, 2.0])
+    m["dof_armature"] = np.asarray(m["dof_armature"], np.float64) + np.r_[np.zeros(6), r.uniform(0.0, 0.02, 12)]
+    m["dof_damping"] = np.asarray(m["dof_damping"], np.float64) * np.r_[np.ones(6), r.uniform(0.6, 1.6, 12)]
+    g = r.uniform(25.0, 45.0, 12); m["act_gain"] = g
+    b = np.asarray(m["act_bias"], np.float64).copy(); b[:, 1] = -g; b[:, 2] = -r.uniform(0.2, 1.0, 12); m["act_bias"] = b
+    m["act_forcerange"] = np.stack([-r.uniform(8, 14, 12), r.uniform(8, 14, 12)], 1)
+    cr = np.asarray(m["act_ctrlrange"], np.float64); m["act_ctrlrange"] = np.stack([cr[:, 0] + 0.1, cr[:, 1] - 0.1], 1)
+    m["foot_geom_pos"] = m["foot_geom_pos"] + r.uniform(-0.004, 0.004, (4, 3)); m["foot_radius"] = np.array([0.02, 0.019, 0.021, 0.0205])
+    m["foot_site_pos"] = m["foot_site_pos"] + r.uniform(-0.004, 0.004, (4, 3)); m["imu_pos"] = m["imu_pos"] + r.uniform(-0.01, 0.01, 3)
+    m["foot_friction"] = np.array([0.7, 0.005, 0.0001]); m["floor_friction"] = np.array([0.8, 0.005, 0.0001]); m["box_friction"] = np.array([0.55, 0.005, 0.0001])
+    for k in ("foot", "floor", "box"):
+        m[k + "_solref"] = np.array([0.02 + 0.004 * r.uniform(), 0.9 + 0.2 * r.uniform()]); m[k + "_solimp"] = np.array([0.7 + 0.2 * r.uniform(), 0.96, 0.002 + 0.02 * r.uniform(), 0.5, 2.0])
+        m[k + "_solmix"] = 0.5 + r.uniform()
+    # the plane contact takes any margin (here + 1 mm: rows of feet that hover become active); foot-box pairs need a mixed margin <= 0 (pgtt_create refuses more)
+    m["foot_margin"] = -0.0005; m["box_margin"] = -0.001; m["floor_margin"] = 0.0015; m["floor_gap"] = 0.0005
+    m["gravity"] = np.array([0.4, -0.3, -9.6]); m["impratio"] = 60.0; m["tolerance"] = 1e-7; m["ls_tolerance"] = 0.02
+    m["iterations"] = 6; m["ls_iterations"] = 7; m["max_geom_pairs"] = 17; m["max_contact_points"] = 3; m["box_rbound"] = 1.5
+    kq = np.asarray(m["key_qpos"], np.float64).copy(); kq[2] = 0.30; kq[7:] += np.tile([0.05, -0.1, 0.15], 4); m["key_qpos"] = kq
+    if axes:
+        ax = np.asarray(m["jnt_axis"], np.float64) + r.normal(size=(12, 3)) * 0.08; m["jnt_axis"] = ax / np.linalg.norm(ax, axis=1, keepdims=True)
+    return m
+
+
+@pytest.mark.parametrize("task", ["stairs", "flat_terrain"])
+def test_model_values_are_read_not_assumed(layout, task):
+    """the kernels take the robot from PgttModel, not from constants: a model of the same topology with EVERY numeric field changed (perturbed_model) goes
+    through the parity bar, oracle and kernels reading the same struct - narrow joint ranges and tight force ranges make limit rows and actuator clipping
+    active, 6 Newton / 7 line-search iterations, max_geom_pairs = 17 and max_contact_points = 3 move every cut of the solver and the collision stage"""
+    terrain = np.load(os.path.join(ASSETS, "terrains", "level4.npy")) if task == "stairs" else None
+    st = run_parity(task, 128, terrain, steps=24, model=perturbed_model(task, axes=True), w_floor=0.55, cap_scale=2.0, med_tol=4e-6)        # hinge axes tilted by ~5 degrees too
+    assert st["active_contacts"] > 1500
 
 
 def test_terrain_table_beyond_32_bit_offsets_is_refused():
