@@ -489,6 +489,33 @@ def test_model_values_are_read_not_assumed(layout, task):
     assert st["active_contacts"] > 1500
 
 
+def random_box_terrain(seed, nplaced):
+    """boxes with ANY orientation (uniform random quaternions), half-sizes 2 - 35 cm, centres scattered over the spawn area at heights that leave their highest
+    corners 0 - 30 cm above the floor, overlapping at random: corners, edges and steep faces under the feet, scan rays through tilted boxes"""
+    r = np.random.default_rng(seed)
+    T = []
+    for v in range(6):
+        rows = []
+        for _ in range(nplaced):
+            q = r.normal(size=4); q /= np.linalg.norm(q)
+            size = r.uniform(0.02, 0.35, 3)
+            reach = float(np.abs(size).sum())                # upper bound of the box's vertical half extent in any orientation
+            rows.append([r.uniform(-1.3, 1.3), r.uniform(-1.3, 1.3), r.uniform(0.0, 0.3) - 0.6 * reach, *q, *size])
+        rows += [[100.0 + n, 100.0 + n, 100.0 + n, 1, 0, 0, 0, 0.5, 0.5, 0.5] for n in range(100 - nplaced)]
+        T.append(rows)
+    return np.asarray(T, dtype=np.float32)
+
+
+@pytest.mark.parametrize("nplaced", [25, 100])
+def test_random_box_terrain_parity(layout, nplaced):
+    """collision, contact frames, top-k selection and the scan on boxes nobody arranged: 25 or all 100 boxes per variant thrown at random (any orientation, any
+    overlap) - sphere-box contacts on faces, edges and corners of rotated boxes, feet inside several boxes at once (the exact many-box pass where needed),
+    rays through tilted boxes; the full bar against the oracle"""
+    terrain = random_box_terrain(17 + nplaced, nplaced)
+    st = run_parity("stairs", 160, terrain, steps=24, w_floor=0.45, cap_scale=3.0, med_tol=6e-6)
+    assert st["box_contacts"] > 800
+
+
 def test_terrain_table_beyond_32_bit_offsets_is_refused():
     """the quad / oct kernels address the terrain table and the cell grid through 32-bit byte offsets from their bases: a table that does not fit is a
     PGTT_E_ARG of pgtt_set_terrain (checked before the table is read), not a wrapped offset"""

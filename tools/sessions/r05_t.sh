@@ -1,0 +1,2 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r05t; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_parity.py -q -m gpu -s -k "random_box" > $O/pytest.log 2>&1; echo "rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed|^E  |env-steps in W|well_frac" $O/pytest.log | cut -c1-500 | tail -24
