@@ -516,6 +516,54 @@ def test_random_box_terrain_parity(layout, nplaced):
     assert st["box_contacts"] > 800
 
 
+def test_extreme_states_parity(layout):
+    """ONE control step from states no roll-out of this suite visits: any base orientation (robots on their backs: termination), bases 5 - 60 cm above the
+    floor or the stairs (feet deep inside boxes or in the air), joints up to 20 % beyond their ranges (limit rows at work), joint speeds up to 12 rad/s,
+    base spins up to 6 rad/s, a stale warm start - the oracle from the identical state, the bar on W; everything finite everywhere"""
+    terrain = np.load(os.path.join(ASSETS, "terrains", "level4.npy"))
+    n = 512
+    env, hb, cs, ms = make_pair("stairs", n, terrain)
+    h64 = oracle.HostBuffers(n, with_variant=True); h64["variant"][...] = hb["variant"]
+    env.reset(3)
+    torch.cuda.synchronize()
+    r = np.random.default_rng(21)
+    model = mjcf.load_model("stairs")
+    jr = np.asarray(model["jnt_range"], np.float64); mid, half = jr.mean(1), 0.5 * (jr[:, 1] - jr[:, 0])
+    S = env.buffers["state"].cpu().numpy()
+    q = r.normal(size=(4, n)); q /= np.linalg.norm(q, axis=0, keepdims=True)
+    upright = r.uniform(size=n) < 0.5                          # half of them keep a near-upright base (otherwise nearly every env would be terminal)
+    yaw = r.uniform(-3.14, 3.14, n); tilt = r.normal(size=(2, n)) * 0.15
+    qu = np.stack([np.cos(yaw / 2), tilt[0], tilt[1], np.sin(yaw / 2)]); qu /= np.linalg.norm(qu, axis=0, keepdims=True)
+    S[3:7] = np.where(upright[None], qu, q)
+    S[0:2] = r.uniform(-1.0, 1.0, (2, n)); S[2] = r.uniform(0.05, 0.6, n)
+    S[7:19] = (mid[:, None] + half[:, None] * r.uniform(-1.2, 1.2, (12, n)))
+    S[19:22] = r.uniform(-1.5, 1.5, (3, n)); S[22:25] = r.uniform(-6.0, 6.0, (3, n)); S[25:37] = r.uniform(-12.0, 12.0, (12, n))
+    S[37:55] = r.normal(size=(18, n)) * 30.0
+    env.buffers["state"].copy_(torch.from_numpy(S))
+    sync_to_host(env, hb, h64)
+    act = np.tanh(r.normal(size=(n, 12))).astype(np.float32)
+    env.step(torch.from_numpy(act).cuda())
+    r64 = np.zeros(n)
+    oracle.step(cs, ms, terrain, hb, act, seed=3, nthreads=8)
+    oracle.step(cs, ms, terrain, h64, act, seed=3, nthreads=8, fp64=True, resid=r64)
+    torch.cuda.synchronize()
+    g = {k: v.cpu().numpy() for k, v in env.buffers.items()}
+    assert all(np.isfinite(g[k]).all() for k in ("state", "frame", "obs_state", "obs_priv", "reward", "metrics", "scan_z"))
+    assert np.array_equal(g["istate"], hb["istate"])
+    eg, ef = per_env_errors(g, hb), per_env_errors(hb.arrays, h64)
+    well = (r64 < 1e-6) & (ef["qpos"] < 1e-5) & (ef["qvel"] < 1e-3)
+    ga, ha = active_sets(g["dbg_contact"], g["dbg_dist"]), active_sets(hb["dbg_contact"], hb["dbg_dist"])
+    sm = np.array([a != b for a, b in zip(ga, ha)])
+    deep = sum(1 for e in range(n) for d in hb["dbg_dist"][e] if d < -0.0175)
+    print(f"\n[extreme states, {layout}] W {well.mean():.2f}; done {int(hb['done'].sum())} of {n}; contacts deeper than the foot radius {deep}; on W: qpos > 1e-4 {(eg['qpos'][well] > 1e-4).sum()}, "
+          f"qvel > 5e-3 {(eg['qvel'][well] > 5e-3).sum()}, ACTIVE-set mismatches {(sm & well).sum()}, done mismatches {((g['done'] != hb['done']) & well).sum()}")
+    assert well.mean() > 0.3 and 0.2 * n < hb["done"].sum() < 0.8 * n and deep > 50
+    assert (eg["qpos"][well] > 1e-4).sum() <= max(2, 0.01 * well.sum()) and (eg["qvel"][well] > 5e-3).sum() <= max(2, 0.01 * well.sum())
+    assert (sm & well).sum() <= 1 and ((g["done"] != hb["done"]) & well).sum() == 0
+    assert np.abs(g["scan_z"] - hb["scan_z"])[well].max() < 1e-4 or (np.abs(g["scan_z"] - hb["scan_z"])[well].max(1) > 1e-5).sum() <= 2
+    env.close()
+
+
 def test_terrain_table_beyond_32_bit_offsets_is_refused():
     """the quad / oct kernels address the terrain table and the cell grid through 32-bit byte offsets from their bases: a table that does not fit is a
     PGTT_E_ARG of pgtt_set_terrain (checked before the table is read), not a wrapped offset"""
