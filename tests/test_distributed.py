@@ -124,6 +124,18 @@ def test_bench_loop_world2_spawned_gloo():
     assert abs(d["value"] - d["env_steps_allreduced"] / (d["ms_per_step"] * 1e-3 * 45)) < 1e-6 * d["value"]
 
 
+def test_bench_loop_world8_spawned_gloo():
+    """the shape of the run the driver makes on an 8-GPU node (BASELINE configs[4]: eight ranks), on the gloo test hook: eight spawned ranks, every one's
+    env-steps in the all-reduced count, one JSON line, one `ranks_dt` entry per rank"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--steps", "40", "--warmup", "3", "--envs", "32"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _bench_line(p.stdout)
+    assert d["n_gpus"] == 8 and d["env_steps_allreduced"] == d["env_steps_expected"] == 8 * 32 * 40 and "error" not in d
+    assert len(d["ranks_dt"]) == 8 and min(d["ranks_dt"]) > 0 and "x8" in d["config"]["parallelism"]
+
+
 def test_bench_loop_world2_torchrun_env_gloo():
     """the driver's launch form: ranks from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run)"""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29612", WORLD_SIZE="2")
