@@ -77,7 +77,8 @@ def _run_case(g, i, ms, cs, fp64, method="pgtt"):
     np.ctypeslib.as_array(pin.site_imu_mat)[:] = k("site_imu_mat").reshape(-1)
     np.ctypeslib.as_array(pin.contact)[:] = k("contact")
     L = oracle.lib()
-    L.pgtt_oracle_set_rng_override(1)
+    L.pgtt_oracle_set_rng_override_value.argtypes = [C.c_float]
+    L.pgtt_oracle_set_rng_override_value(C.c_float(float(k("frac"))))          # the pinned draw the reference ran this case with (0.5 unless `draws`)
     try:
         b = hb.struct()
         L.pgtt_oracle_task_post(C.byref(cs), C.byref(ms), C.byref(b), C.byref(pin), int(fp64))
@@ -86,15 +87,20 @@ def _run_case(g, i, ms, cs, fp64, method="pgtt"):
     return hb
 
 
-@pytest.mark.parametrize("source", ["synthetic", "rollout"])
+_STEP_FILES = {"synthetic": "task_step", "rollout": "task_step_rollout", "draws": "task_step_draws"}
+
+
+@pytest.mark.parametrize("source", ["synthetic", "rollout", "draws"])
 @pytest.mark.parametrize("method", ["pgtt", "baseline"])
 @pytest.mark.parametrize("fp64", [True, False])
 def test_task_step_against_reference(golden_dir, ms, fp64, method, source):
     """go2/joystick_pgtt.py (method pgtt) and go2/joystick.py (method baseline) executed end to end by the reference's
     own Python (tools/gen_golden.py) vs the oracle's task layer - on 14 synthetic states per task (`synthetic`) and CLOSED LOOP along roll-outs whose
-    physics outputs come from the oracle (`rollout`: 240 / 120 consecutive steps of 6 / 4 robots; the reference carries its own `info` from step to step)"""
+    physics outputs come from the oracle (`rollout`: 240 / 120 consecutive steps of 6 / 4 robots; the reference carries its own `info` from step to step).
+    `draws`: both kinds again with every uniform draw pinned to 0.2 / 0.4 / 0.7 instead of 0.5 - the noise terms of _get_obs are then (2u - 1) * scale != 0
+    (joystick_pgtt.py:242-285, configs.py:19-29) and sample_command takes its w = 1 branches (joystick_pgtt.py:603-611)"""
     from conftest import GoldenCases
-    g = GoldenCases(os.path.join(golden_dir, ("task_step" if source == "synthetic" else "task_step_rollout") + ("" if method == "pgtt" else "_baseline") + ".npz"))
+    g = GoldenCases(os.path.join(golden_dir, _STEP_FILES[source] + ("" if method == "pgtt" else "_baseline") + ".npz"))
     cs = abi.config_struct(configs.training_config(method))
     od, pd = abi.obs_dims(method)
     assert g["c0_obs"].shape == (od,) and g["c0_priv"].shape == (pd,)
@@ -124,6 +130,35 @@ def test_task_step_against_reference(golden_dir, ms, fp64, method, source):
         assert np.array_equal(S[abi.S_LAST_CONTACT:abi.S_LAST_CONTACT + 4], k("out_last_contact")), i
         assert I[abi.I_STEP] == int(k("out_step")), i
         assert I[abi.I_STEPS_UNTIL_CMD] == int(k("out_steps_until_next_cmd")), (i, I[abi.I_STEPS_UNTIL_CMD], k("out_steps_until_next_cmd"))
+
+
+@pytest.mark.parametrize("method", ["pgtt", "baseline"])
+def test_draws_fixture_takes_the_stochastic_branches(golden_dir, method):
+    """what task_step_draws*.npz hold, read off the REFERENCE's outputs alone (no oracle, no kernel): every noisy observation block differs from its
+    noise-free source by exactly (2 FRAC - 1) * level * scale with the scales of go2/configs.py:19-29 as configs.py states them, and the command changes
+    in >= 20 records (sample_command's w = 1 branch, joystick_pgtt.py:603-611) while it never changes at FRAC = 0.7 (w = 0)"""
+    g = np.load(os.path.join(golden_dir, "task_step_draws" + ("" if method == "pgtt" else "_baseline") + ".npz"))
+    cfg = configs.training_config(method)
+    cs = abi.config_struct(cfg)
+    f, obs = g["frac"], g["obs"].astype(np.float64)
+    assert sorted(set(np.round(f, 6))) == [0.2, 0.4, 0.7] and float(cs.noise_level) == 1.0
+    amp = (2 * f - 1)[:, None]
+    pose = np.array([0.0, 0.9, -1.8] * 4)
+    o_scan = 38 if method == "pgtt" else 30          # gyro 3, gravity 3, q 12, qd 12, (cos, sin 8: PGTT only), scan 117
+    z = g["scan_z"].astype(np.float64)
+    for name, got, clean, scale in (("gyro", obs[:, 0:3], g["sensordata"][:, 0:3], cs.noise_gyro), ("gravity", obs[:, 3:6], -g["site_imu_mat"][:, 2], cs.noise_gravity),
+                                    ("joint_pos", obs[:, 6:18], g["qpos"][:, 7:] - pose, cs.noise_joint_pos), ("joint_vel", obs[:, 18:30], g["qvel"][:, 6:], cs.noise_joint_vel),
+                                    ("heightscan", obs[:, o_scan:o_scan + 117], z - z.min(1, keepdims=True), cs.noise_heightscan)):
+        assert np.abs((got - clean) - amp * float(scale)).max() < 2e-6, name
+    changed = (g["out_command"] != g["in_command"]).any(1)
+    resampled = g["in_steps_until_next_cmd"] - 1 <= 0
+    assert changed.sum() >= 20 and not changed[f > 0.5].any() and resampled.sum() >= 100 and not changed[~resampled].any()
+    # z = [1, 1, 1] at 0.2, [1, 0, 1] at 0.4 (b = .9, .25, .5): the middle command is the draw at 0.2 and exactly 0 at 0.4
+    y = np.asarray(cs.cmd_u_min) + f[:, None] * (np.asarray(cs.cmd_u_max) - np.asarray(cs.cmd_u_min))
+    sel = resampled & (f < 0.5)
+    assert np.abs(g["out_command"][sel][:, [0, 2]] - y[sel][:, [0, 2]]).max() < 1e-6
+    assert np.abs(g["out_command"][sel & (f < 0.3)][:, 1] - y[sel & (f < 0.3)][:, 1]).max() < 1e-6 and not g["out_command"][sel & (f > 0.3)][:, 1].any()
+    assert sorted(set(g["out_steps_until_next_cmd"][resampled].astype(int))) == [56, 128, 301]      # round(-log1p(-FRAC) * 5 / 0.02)
 
 
 @pytest.mark.parametrize("fp64", [True, False])

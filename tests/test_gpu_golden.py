@@ -45,44 +45,58 @@ def _load_step_cases(g, env, method):
     return S, I, F, Z, A
 
 
-@pytest.mark.parametrize("source", ["synthetic", "rollout"])
+_STEP_FILES = {"synthetic": "task_step", "rollout": "task_step_rollout", "draws": "task_step_draws"}
+
+
+@pytest.mark.parametrize("source", ["synthetic", "rollout", "draws"])
 @pytest.mark.parametrize("observe", ["fused", "split"])
 @pytest.mark.parametrize("method", ["pgtt", "baseline"])
 def test_observe_kernel_against_reference_step(golden_dir, method, observe, source):
     """observe_kernel (scan statistics, observation rows, 21 rewards, bookkeeping) on the reference's own Joystick.step vectors: 14 synthetic states per task
-    and the closed-loop roll-out records (240 / 120 consecutive steps; tools/gen_golden.py)"""
+    and the closed-loop roll-out records (240 / 120 consecutive steps; tools/gen_golden.py).  `draws` (round 6): the same two kinds recorded with every
+    uniform draw pinned to 0.2 / 0.4 / 0.7 - noise terms (2u - 1) * scale != 0 in the five noisy blocks (joystick_pgtt.py:242-285, configs.py:19-29) and
+    sample_command's w = 1 branch with z = [1,1,1] / [1,0,1] (joystick_pgtt.py:603-611); one launch per pinned value, each case compared under its own"""
     from conftest import GoldenCases
     from phase_guided_terrain_traversal_amd.env import Joystick
-    g = GoldenCases(os.path.join(golden_dir, ("task_step" if source == "synthetic" else "task_step_rollout") + ("" if method == "pgtt" else "_baseline") + ".npz"))
+    g = GoldenCases(os.path.join(golden_dir, _STEP_FILES[source] + ("" if method == "pgtt" else "_baseline") + ".npz"))
     n = g.ncases
     env = Joystick("flat_terrain", configs.training_config(method), num_envs=n, device="cuda:0", observe_form=observe, test_hooks=True)
     env.reset(seed=0)          # allocates / initialises everything; the rows the step reads are then overwritten
     S, I, F, Z, A = _load_step_cases(g, env, method)
-    env.buffers["state"].copy_(torch.from_numpy(S)); env.buffers["istate"].copy_(torch.from_numpy(I))
-    env.buffers["frame"].copy_(torch.from_numpy(F)); env.buffers["scan_z"].copy_(torch.from_numpy(Z))
-    env.set_test_overrides(rng_value=0.5, scan_preset=True)
-    env.observe(torch.from_numpy(A).cuda())
-    torch.cuda.synchronize()
-    b = {k: v.cpu().numpy().astype(np.float64) for k, v in env.buffers.items()}
+    fracs = np.array([float(g[f"c{i}_frac"]) for i in range(n)])
     od, pd = abi.obs_dims(method)
-    assert b["obs_state"].shape == (n, od) and b["obs_priv"].shape == (n, pd)
-    npos = 0
-    for i in range(n):
-        k = lambda name: g[f"c{i}_{name}"]
-        St, It = b["state"][:, i], b["istate"][:, i]
-        assert np.abs(b["obs_state"][i] - k("obs")).max() < TOL, i
-        assert np.abs(b["obs_priv"][i] - k("priv")).max() < TOL, i
-        assert abs(b["reward"][i] - k("reward")) < TOL, i
-        npos += k("reward") > 0
-        assert b["done"][i] == k("done"), i
-        assert np.abs(b["metrics"][:, i] - k("metrics")).max() < TOL * max(1.0, np.abs(k("metrics")).max()), i
-        for off, cnt, name in ((abi.S_CMD, 3, "command"), (abi.S_PHASE, 4, "phase"), (abi.S_LAST_ACT, 12, "last_act"),
-                               (abi.S_LAST_LAST_ACT, 12, "last_last_act"), (abi.S_AIR_TIME, 4, "feet_air_time"), (abi.S_SWING_PEAK, 4, "swing_peak"),
-                               (abi.S_HMAX, 4, "H_max"), (abi.S_HMIN, 4, "H_min"), (abi.S_MOTOR_TARGETS, 12, "motor_targets"),
-                               (abi.S_QERR_HIST, 24, "qpos_error_history"), (abi.S_QVEL_HIST, 24, "qvel_history"), (abi.S_LAST_CONTACT, 4, "last_contact")):
-            assert np.abs(St[off:off + cnt] - k("out_" + name)).max() < TOL, (i, name)
-        assert It[abi.I_STEP] == int(k("out_step")) and It[abi.I_STEPS_UNTIL_CMD] == int(k("out_steps_until_next_cmd")), i
+    npos = nchanged = nnoisy = 0
+    for f in np.unique(fracs):
+        env.buffers["state"].copy_(torch.from_numpy(S)); env.buffers["istate"].copy_(torch.from_numpy(I))
+        env.buffers["frame"].copy_(torch.from_numpy(F)); env.buffers["scan_z"].copy_(torch.from_numpy(Z))
+        env.set_test_overrides(rng_value=float(f), scan_preset=True)
+        env.observe(torch.from_numpy(A).cuda())
+        torch.cuda.synchronize()
+        b = {k: v.cpu().numpy().astype(np.float64) for k, v in env.buffers.items()}
+        assert b["obs_state"].shape == (n, od) and b["obs_priv"].shape == (n, pd)
+        for i in np.nonzero(fracs == f)[0]:
+            k = lambda name: g[f"c{i}_{name}"]
+            St, It = b["state"][:, i], b["istate"][:, i]
+            assert np.abs(b["obs_state"][i] - k("obs")).max() < TOL, i
+            assert np.abs(b["obs_priv"][i] - k("priv")).max() < TOL, i
+            assert abs(b["reward"][i] - k("reward")) < TOL, i
+            npos += k("reward") > 0
+            assert b["done"][i] == k("done"), i
+            assert np.abs(b["metrics"][:, i] - k("metrics")).max() < TOL * max(1.0, np.abs(k("metrics")).max()), i
+            for off, cnt, name in ((abi.S_CMD, 3, "command"), (abi.S_PHASE, 4, "phase"), (abi.S_LAST_ACT, 12, "last_act"),
+                                   (abi.S_LAST_LAST_ACT, 12, "last_last_act"), (abi.S_AIR_TIME, 4, "feet_air_time"), (abi.S_SWING_PEAK, 4, "swing_peak"),
+                                   (abi.S_HMAX, 4, "H_max"), (abi.S_HMIN, 4, "H_min"), (abi.S_MOTOR_TARGETS, 12, "motor_targets"),
+                                   (abi.S_QERR_HIST, 24, "qpos_error_history"), (abi.S_QVEL_HIST, 24, "qvel_history"), (abi.S_LAST_CONTACT, 4, "last_contact")):
+                assert np.abs(St[off:off + cnt] - k("out_" + name)).max() < TOL, (i, name)
+            assert It[abi.I_STEP] == int(k("out_step")) and It[abi.I_STEPS_UNTIL_CMD] == int(k("out_steps_until_next_cmd")), i
+            # what the case exercises, counted on the KERNEL's outputs: a command that changed, a gyro row that carries noise
+            nchanged += bool(np.abs(St[abi.S_CMD:abi.S_CMD + 3] - S[abi.S_CMD:abi.S_CMD + 3, i]).max() > 1e-3)
+            nnoisy += bool(np.abs(b["obs_state"][i, :3] - F[abi.F_GYRO:abi.F_GYRO + 3, i]).min() > 0.05)
     assert npos >= 2           # the fixtures include un-clipped positive totals
+    if source == "draws":      # the point of these records: the stochastic branches are taken, by the kernel, with the reference's numbers
+        assert nchanged >= 20 and nnoisy == n, (nchanged, nnoisy)
+    else:
+        assert nchanged == 0 and nnoisy == 0
     env.close()
 
 

@@ -17,6 +17,11 @@ text is stored; the reference is never shipped.  Fixtures:
                      jax.random stubbed (uniform -> 0.5, bernoulli -> 0.5 < p, exponential ->
                      -log1p(-0.5)):  obs[171], privileged[215], reward, done, 21 metrics and every
                      info field after the step                                 (joystick_pgtt.py:141-231)
+  task_step_draws.npz, task_step_draws_baseline.npz   (round 6) the same records with every uniform draw pinned to
+                     FRAC in {0.2, 0.4, 0.7} at noise level 1.0: the five noise terms of _get_obs become
+                     (2 FRAC - 1) * scale (joystick_pgtt.py:242-285, configs.py:19-29) and sample_command takes
+                     its w = 1 branches with z = [1,1,1] / [1,0,1] (joystick_pgtt.py:603-611): 14 synthetic
+                     states + a closed-loop roll-out per FRAC, command timers capped so that commands resample
   task_step_baseline.npz  the same for the baseline task go2/joystick.py + configs.baseline_config()
   scan_grid_cpu_twin.npz  deploy/cpu_heightmap/heightmap.create_sensor_matrix (numpy + mujoco.mj_ray stubbed)
   domain_randomize.npz    go2/randomize.py and randomize_simple.py on a numpy stand-in of mjx.Model with every uniform
@@ -90,7 +95,9 @@ jrandom.split = lambda key, n=2: tuple(key for _ in range(n))
 FRAC = [0.5]      # every uniform draw returns minval + FRAC * (maxval - minval); 0.5 for the task fixtures
 jrandom.uniform = lambda key, shape=(), minval=0.0, maxval=1.0: (FRAC[0] * (np.asarray(maxval) - np.asarray(minval)) + np.asarray(minval)) * np.ones(shape)
 jrandom.randint = lambda key, shape=(), minval=0, maxval=1: (int(minval) + int(FRAC[0] * (int(maxval) - int(minval) - 1))) * np.ones(shape, dtype=np.int64)
-jrandom.bernoulli = lambda key, p=0.5, shape=(): (0.5 < np.asarray(p)) * np.ones(shape, dtype=bool)
+# jax.random.bernoulli(key, p, shape) IS `uniform(key, shape) < p` [UPSTREAM-RECALL: jax/_src/random.py]; the stub keeps that form on the pinned draw, so
+# FRAC = 0.2 gives z = [1, 1, 1], w = 1; 0.4 gives z = [1, 0, 1], w = 1; 0.5 / 0.7 give z = [1, 0, 0], w = 0 for b = [.9, .25, .5] (joystick_pgtt.py:603-611)
+jrandom.bernoulli = lambda key, p=0.5, shape=(): (FRAC[0] < np.asarray(p)) * np.ones(shape, dtype=bool)
 jrandom.exponential = lambda key, shape=(): -np.log1p(-FRAC[0]) * np.ones(shape)
 jrandom.PRNGKey = lambda s: np.zeros(2, dtype=np.uint32)
 
@@ -283,8 +290,9 @@ class FakeData:
     pass
 
 
-def gen_cases(mod, cfg, rng):
+def gen_cases(mod, cfg, rng, frac=0.5):
     cases = []
+    FRAC[0] = frac
     for case in range(14):        # 12, 13: calm states that track the command -> POSITIVE total reward (un-clipped branch)
         env = make_env(mod, cfg)
         d = FakeData()
@@ -346,7 +354,7 @@ def gen_cases(mod, cfg, rng):
             site_foot_z=d.site_xpos[env._feet_site_id][:, 2], actuator_force=d.actuator_force, action=action,
             scan_z=scan[..., 2].ravel(), contact=contact.astype(np.int32),
             obs=np.asarray(out.obs["state"], dtype=np.float64), priv=np.asarray(out.obs["privileged_state"], dtype=np.float64),
-            reward=float(out.reward), done=float(out.done),
+            reward=float(out.reward), done=float(out.done), frac=np.float64(frac),
             metrics=np.array([float(out.metrics[f"reward/{k}"]) for k in
                               ["tracking_lin_vel", "tracking_ang_vel", "lin_vel_z", "ang_vel_xy", "orientation", "dof_pos_limits",
                                "pose", "termination", "stand_still", "torques", "action_rate", "energy", "feet_clearance",
@@ -359,6 +367,7 @@ def gen_cases(mod, cfg, rng):
             if k not in ("rng", "heightscan"):
                 rec["out_" + k] = np.array(v, dtype=np.float64)
         cases.append(rec)
+    FRAC[0] = 0.5
     return cases
 
 
@@ -389,7 +398,8 @@ _METRIC_KEYS = ["tracking_lin_vel", "tracking_ang_vel", "lin_vel_z", "ang_vel_xy
                 "action_rate", "energy", "feet_clearance", "feet_height", "feet_slip", "feet_air_time", "feet_phase", "feet_swing", "body_height", "contact", "center"]
 
 
-def gen_rollout_cases(mod, cfg, method, task, terrain, n_env, n_steps, seed):
+def gen_rollout_cases(mod, cfg, method, task, terrain, n_env, n_steps, seed, frac=0.5, timer_cap=None):
+    FRAC[0] = frac
     ocfg = _cfgs.training_config(method)
     cs, ms = _abi.config_struct(ocfg), _abi.model_struct(_mjcf.load_model(task))
     hb = _orc.HostBuffers(n_env, with_variant=terrain is not None, method=method)
@@ -434,6 +444,9 @@ def gen_rollout_cases(mod, cfg, method, task, terrain, n_env, n_steps, seed):
             mod.create_sensor_matrix = lambda mx, dx, center, yaw=0.0, scan=scan: scan.view(AtArray)
             env.compute_contact = lambda data, a, b, contact=contact: contact
             env.get_yaw = lambda data: 0.0
+            if timer_cap is not None and int(info["steps_until_next_cmd"]) > timer_cap:
+                # the pinned exponential draw gives timers of 56 / 128 / 301 steps: cap them (an INPUT of the recorded case) so that commands resample often
+                info["steps_until_next_cmd"] = np.int64(1 + (3 * e + t) % timer_cap)
             info_in = {k: np.array(v, dtype=np.float64) for k, v in info.items() if k not in ("rng", "heightscan")}
             action = act[e].astype(np.float64)
             out = env.step(State(FakeData(), None, 0.0, 0.0, metrics[e], info), action.view(AtArray))
@@ -442,7 +455,7 @@ def gen_rollout_cases(mod, cfg, method, task, terrain, n_env, n_steps, seed):
                        obs=np.asarray(out.obs["state"], dtype=np.float64), priv=np.asarray(out.obs["privileged_state"], dtype=np.float64),
                        reward=float(out.reward), done=float(out.done),
                        metrics=np.array([float(out.metrics[f"reward/{k}"]) for k in _METRIC_KEYS] + [float(out.metrics["swing_peak"])]),
-                       env=np.int32(e), t=np.int32(t))
+                       env=np.int32(e), t=np.int32(t), frac=np.float64(frac))
             for k, v in info_in.items():
                 rec["in_" + k] = v
             for k, v in out.info.items():
@@ -450,6 +463,7 @@ def gen_rollout_cases(mod, cfg, method, task, terrain, n_env, n_steps, seed):
                     rec["out_" + k] = np.array(v, dtype=np.float64)
             cases.append(rec)
             infos[e], metrics[e] = out.info, out.metrics          # closed loop on the reference's own bookkeeping
+    FRAC[0] = 0.5
     return cases
 
 
@@ -466,6 +480,29 @@ for _name, _mod, _c, _method, _task, _terr, _n, _T in (("task_step_rollout.npz",
     np.savez_compressed(os.path.join(OUT, _name), layout=np.array("stacked"), ncases=len(_cases), **_stk)
     print(_name, len(_cases), "cases,", sum(c["done"] for c in _cases), "terminal,", sum(c["reward"] > 0 for c in _cases), "with positive reward,",
           sum(int(c["in_steps_until_next_cmd"]) == 1 for c in _cases), "command resamplings,", round(os.path.getsize(os.path.join(OUT, _name)) / 1e6, 2), "MB")
+
+# ------------------------------------------------------------------ the stochastic branches (round 6): task_step_draws*.npz
+# Every record above has FRAC = 0.5: the noise factor (2u - 1) is 0 and sample_command's w is 0, so neither the five noise terms of _get_obs
+# (joystick_pgtt.py:242-285; scales go2/configs.py:19-29) nor the `x - w (x - y z)` branch (joystick_pgtt.py:603-611) are visible in them.  Here the same two
+# generators run with every draw pinned to FRAC in {0.2, 0.4, 0.7} at the config's noise level (1.0): noise terms = (2 FRAC - 1) * scale, w = 1 with
+# z = [1,1,1] (0.2) / [1,0,1] (0.4), w = 0 (0.7), timers = round(-log1p(-FRAC) * 5 / dt).  Own generators: the fixtures before and after this block keep their bits.
+_DRAW_FRACS = (0.2, 0.4, 0.7)
+assert float(cfg.noise_config.level) == 1.0 and float(cfg_b.noise_config.level) == 1.0
+for _name, _mod, _c, _method, _task, _terr, _n, _T, _seed in (("task_step_draws.npz", jpg, cfg, "pgtt", "stairs", _lvl4, 6, 24, 20250930),
+                                                                ("task_step_draws_baseline.npz", jbase, cfg_b, "baseline", "flat_terrain", None, 4, 20, 20250931)):
+    _cases = []
+    for _fi, _f in enumerate(_DRAW_FRACS):
+        _cases += gen_cases(_mod, _c, np.random.default_rng(_seed + _fi), frac=_f)
+        _cases += gen_rollout_cases(_mod, _c, _method, _task, _terr, _n, _T, seed=11 + _fi, frac=_f, timer_cap=5)
+    _keys = [k for k in _cases[0] if all(k in r for r in _cases)]          # the roll-out records carry (env, t) in addition
+    _stk = {}
+    for k in _keys:
+        a = np.stack([np.asarray(r[k]) for r in _cases])
+        _stk[k] = a.astype(np.float32) if a.dtype == np.float64 and k != "frac" else a
+    np.savez_compressed(os.path.join(OUT, _name), layout=np.array("stacked"), ncases=len(_cases), **_stk)
+    _res = [c for c in _cases if int(c["in_steps_until_next_cmd"]) - 1 <= 0]
+    print(_name, len(_cases), "cases,", len(_res), "command resamplings,", sum(bool(np.any(c["out_command"] != c["in_command"])) for c in _cases), "with a changed command,",
+          sum(c["done"] for c in _cases), "terminal,", round(os.path.getsize(os.path.join(OUT, _name)) / 1e6, 2), "MB")
 
 # ------------------------------------------------------------------ domain randomisation (a16): go2/randomize.py, randomize_simple.py
 # executed on a numpy stand-in of mjx.Model (the robot's nominal fields from the compiled model, placeholder boxes) with
