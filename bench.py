@@ -268,7 +268,14 @@ def profile_record(workload, n):
     rec = allrec.get(f"{workload}_{n}", {})
     if not rec:
         return {}, False
-    if allrec.get("_source", {}).get("csrc_sha256") != native.source_sha256():
+    src = allrec.get("_source", {})
+    try:
+        # two guards: the sources on disk (a checkout edited since the counters were taken) AND the library this process actually loaded (a stale
+        # libpgtt.so, or PGTT_LIB pointing at a side build made from the same sources with other flags).  An installed package without csrc/ cannot
+        # be checked: withheld as stale rather than costing the headline line.
+        if src.get("csrc_sha256") != native.source_sha256() or src.get("lib_sha256") != native.library_sha256(native.LIB_PATH):
+            return {}, True
+    except Exception:
         return {}, True
     return rec, False
 
@@ -350,6 +357,7 @@ def graph_row(args, local, dev, sync):
     replays = max(1, max(200, args.other_steps) // T)
     row = {"workload": "graph", "envs": n, "what": f"headline workload, {T} control steps + interval reduction captured as ONE HIP graph, {replays} replays",
            "steps": replays * T, "steps_per_graph": T, "lane_layout": args.layout}
+    env = None
     try:
         t0 = time.perf_counter()
         env, cfg, terrain, task, dr = build_env(a2, 0, 1, local)
@@ -384,9 +392,15 @@ def graph_row(args, local, dev, sync):
         counted = float(total[-1].item())
         row.update(value=counted / dt, unit="env-steps/s", ms_per_step=1e3 * dt / (replays * T), env_steps_counted=counted,
                    env_steps_expected=float(n) * replays * T, setup_s=time.perf_counter() - t0 - dt)
-        env.close()
     except Exception as e:          # a side row must never cost the headline line
         row["skipped"] = f"{type(e).__name__}: {e}"
+        try:
+            torch.cuda.synchronize()          # a poisoned capture surfaces HERE, not in the row that runs next
+        except Exception as e2:
+            row["skipped"] += f" / then {type(e2).__name__}: {e2}"
+    finally:
+        if env is not None:
+            env.close()
     return row
 
 
@@ -404,6 +418,7 @@ def rollout_row(args, local, dev, sync):
     T, steps = REDUCE_EVERY, max(200, args.other_steps)
     row = {"workload": "rollout", "envs": a2.envs, "what": "policy177 forward + sample + env.step + bookkeeping, one HIP graph per acting step, level4 (N1: caller of the hot path)",
            "steps": steps, "unroll_length": T, "lane_layout": args.layout, "launches_per_step": 4}
+    env = None
     try:
         t0 = time.perf_counter()
         env, cfg, terrain, task, dr = build_env(a2, 0, 1, local)
@@ -439,9 +454,15 @@ def rollout_row(args, local, dev, sync):
         es = fa.episode_sums.cpu().numpy()
         row.update(value=a2.envs * n_steps / dt, unit="env-steps/s", steps=n_steps, ms_per_step=1e3 * dt / n_steps,
                    episodes_finished=float(es[-1]), mean_episode_length=float(es[-2] / max(es[-1], 1.0)), setup_s=time.perf_counter() - t0 - dt)
-        env.close()
     except Exception as e:          # a caller-side row must never cost the headline line
         row["skipped"] = f"{type(e).__name__}: {e}"
+        try:
+            torch.cuda.synchronize()
+        except Exception as e2:
+            row["skipped"] += f" / then {type(e2).__name__}: {e2}"
+    finally:
+        if env is not None:
+            env.close()
     return row
 
 
@@ -501,12 +522,12 @@ def worker(args):
         ratio = ms_per_step / kern
         out = {
             "metric": "env-steps/sec at 4096 envs (Go2, level4 hfield), 1/2/4/8 MI355X",
-            "value": value, "unit": "env-steps/s", "n_gpus": ranks, "steps": args.steps, "warmup": w["untimed_steps"],
+            "value": value, "unit": "env-steps/s", "n_gpus": ranks, "steps": args.steps, "warmup": args.warmup, "untimed_steps": w["untimed_steps"],
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD_TEXT[args.workload],
                        "envs_per_gpu": n, "substeps": 4, "autoreset": True, "actions": "tanh(N(0,0.6)) iid", "parallelism": f"env-shard x{world}",
-                       "lane_layout": args.layout, "warmup_arg": args.warmup, "prime_steps": args.prime_steps, "untimed_steps_before_clock": w["untimed_steps"],
+                       "lane_layout": args.layout, "prime_steps": args.prime_steps, "untimed_steps_before_clock": w["untimed_steps"],
                        "terrain_variants": ("per-env draws in draw order (--unsorted-variants)" if args.unsorted_variants else
                                             "randomize.domain_randomize default: per-env draws, ascending within blocks of 4096 global env ids"),
                        "collective": f"fused {MetricReducer.SIZE}-float all-reduce every {REDUCE_EVERY} steps ({args.backend})"},

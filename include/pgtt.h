@@ -6,7 +6,8 @@
  *   mjx_env.step / mjx.forward (un-vendored)   (call sites go2/joystick_pgtt.py:72,78,146-148)
  *   Go2Env.compute_contact                     (go2/base.py:153-171)
  *   create_sensor_matrix / raycast_sensor      (go2/heightmap.py:10-67)
- *   domain_randomize (per-env model fields)    (go2/randomize.py:23-171) -> pgtt_set_params
+ *   domain_randomize (per-env model fields)    (go2/randomize.py:23-171) -> host side (randomize.py), handed over as
+ *                                               PgttBuffers.params / variant / box_friction rows
  *
  * Conventions
  *   - plain C, no torch / HIP types in signatures (`stream` is a hipStream_t passed as void*).
@@ -265,7 +266,9 @@ int pgtt_bind(pgtt_handle h, const PgttBuffers* bufs);
  * streams; draws are a function of (seed, global env id, counter) only, so results do not depend on
  * how envs are sharded over GPUs. `env_id_offset` is the global id of local env 0.
  * With a terrain and per-env variant labels bound, the labels are range-checked first (one launch + a 4-byte read-back: the ONE place where the
- * library waits for `stream`; skipped while the stream is being captured into a graph): PGTT_E_ARG, nothing written, when one is outside [0, T). */
+ * library waits for `stream`): PGTT_E_ARG, nothing written, when one is outside [0, T).  Checked by every whole-batch reset (mask NULL) and by the
+ * first reset of any kind after pgtt_bind / pgtt_set_terrain; a masked reset after that is asynchronous (labels edited in place since are clamped by
+ * the kernels, never used as they are).  Skipped while a stream capture is under way (a capture cannot wait). */
 int pgtt_reset(pgtt_handle h, uint64_t seed, int64_t env_id_offset, const uint8_t* mask_dev_or_null, void* stream);
 
 /* Joystick.step for all envs. action is [N][12] row-major (FR,FL,RR,RL), device pointer. */

@@ -53,6 +53,7 @@ struct pgtt_env {
   float test_rng_fix = NAN; int test_scan_preset = 0;   // pgtt_set_test_overrides
   float* d_handover = nullptr;    // [N][kHandover]: physics -> observe hand-over of one pgtt_step (pgtt_kernels.hip.h, KArgs)
   int* d_flag = nullptr; int* h_flag = nullptr;      // pgtt_reset's range check of the caller's terrain-variant labels (device word, pinned host word)
+  bool labels_unchecked = true;   // set by pgtt_bind / pgtt_set_terrain: the next pgtt_reset of any kind checks the labels; afterwards only whole-batch resets do
   bool timing = false;
   int timing_period = 1, timing_tick = 0; bool timing_now = false;   // time every timing_period-th step (event records cost ~3 us of GPU idle each)
   bool split_observe = false;     // observe = observe_kernel<OBS_STEP_OBS> + task_kernel (PgttConfig.observe_form)
@@ -335,6 +336,7 @@ int pgtt_set_terrain(pgtt_handle h, const float* boxes, int T, int B) {
     HIP_TRY(hipMemcpy(h->d_cull, cull.data(), cull.size() * sizeof(float4), hipMemcpyHostToDevice));
   }
   h->T = T; h->B = B;
+  h->labels_unchecked = true;
   return PGTT_OK;
 }
 
@@ -346,6 +348,7 @@ int pgtt_bind(pgtt_handle h, const PgttBuffers* b) {
     return fail(PGTT_E_ARG, "pgtt_bind: autoreset needs first_state and first_obs");
   h->buf = *b;
   h->bound = true;
+  h->labels_unchecked = true;
   return PGTT_OK;
 }
 
@@ -354,12 +357,15 @@ int pgtt_reset(pgtt_handle h, uint64_t seed, int64_t env_id_offset, const uint8_
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((h->N + 63) / 64), block(64);
-  if (h->T > 0 && h->buf.variant) {
+  if (h->T > 0 && h->buf.variant && (mask == nullptr || h->labels_unchecked)) {
     // every env's terrain-variant label must name one of the T variants of pgtt_set_terrain.  One launch + a 4-byte read-back BEFORE anything is
-    // written; this is the one place where the library waits for the stream (reset is off the steady-state path: AutoReset lives in the step).
-    // Not while the stream is being captured into a graph (a capture cannot wait) - the kernels clamp the label either way.
+    // written; this is the one place where the library waits for the stream.  Whole-batch resets (mask NULL: off the steady-state path, AutoReset
+    // lives in the step) always check; a MASKED reset - the form a caller may put into its loop - checks only when pgtt_bind / pgtt_set_terrain
+    // ran since the last check and is otherwise asynchronous like every other entry point.  Not while a capture is under way (a capture cannot
+    // wait; the query itself fails with hipErrorStreamCaptureImplicit on the null stream while ANOTHER stream captures in global mode: treated as
+    // "capturing") - the kernels clamp the label either way.
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    HIP_TRY(hipStreamIsCapturing(st, &cap));
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
     if (cap == hipStreamCaptureStatusNone) {
       HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(int), st));
       hipLaunchKernelGGL(variant_range_kernel, grid, block, 0, st, h->buf.variant, h->N, h->T, h->d_flag);
@@ -367,6 +373,7 @@ int pgtt_reset(pgtt_handle h, uint64_t seed, int64_t env_id_offset, const uint8_
       HIP_TRY(hipStreamSynchronize(st));
       if (*h->h_flag != 0)
         return fail(PGTT_E_ARG, "pgtt_reset: " + std::to_string(*h->h_flag) + " terrain variant label(s) outside [0, " + std::to_string(h->T) + ") in PgttBuffers.variant");
+      h->labels_unchecked = false;
     }
   }
   h->seed = seed; h->env_off = env_id_offset;

@@ -115,8 +115,9 @@ def test_bench_loop_world2_spawned_gloo():
     assert p.returncode == 0, p.stderr[-2000:]
     d = _bench_line(p.stdout)
     assert d["stub"] is True and d["n_gpus"] == 2 and d["steps"] == 45
-    # top-level "warmup" = EVERY untimed step before the clock (code-path priming 40 + prime 100 in the stub + the 5 asked for); the argument stays in config
-    assert d["warmup"] == d["config"]["untimed_steps_before_clock"] == 40 + 100 + 5 and d["config"]["warmup_arg"] == 5
+    # top-level "warmup" echoes --warmup (the driver checks it against its command line); EVERY untimed step before the clock (code-path priming 40 +
+    # prime 100 in the stub + the 5 asked for) is `untimed_steps`
+    assert d["warmup"] == 5 and d["untimed_steps"] == d["config"]["untimed_steps_before_clock"] == 40 + 100 + 5
     # one entry per rank, each rank's own time for its K steps before the closing barrier; the clock is their maximum (+ the barrier)
     assert len(d["ranks_dt"]) == 2 and all(0 < t <= d["ms_per_step"] * 1e-3 * 45 * 1.0001 for t in d["ranks_dt"])
     # the all-reduced env-step count proves both ranks contributed every interval, tail included (45 = 2 x 20 + 5)

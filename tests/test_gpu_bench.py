@@ -29,9 +29,10 @@ def test_driver_command_line_contract():
     assert abs(d["value"] - d["env_steps_allreduced"] / (d["ms_per_step"] * 1e-3 * 20)) < 1e-6 * d["value"]
     assert d["value"] > 15e6                                     # target of the north star: 1 M; measured 22 - 23 M
     c = d["config"]
-    assert "level4" in c["workload"] and c["envs_per_gpu"] == 4096 and c["prime_steps"] >= 100 and c["warmup_arg"] == 5
-    # top-level "warmup": every untimed step before the clock (40 code-path priming steps + prime_steps + the 5 of the command line)
-    assert d["warmup"] == c["untimed_steps_before_clock"] == 40 + c["prime_steps"] + 5
+    assert "level4" in c["workload"] and c["envs_per_gpu"] == 4096 and c["prime_steps"] >= 100
+    # top-level "warmup" echoes the command line (the driver compares the two); every untimed step before the clock (40 code-path priming steps +
+    # prime_steps + those 5) is `untimed_steps`
+    assert d["warmup"] == 5 and d["untimed_steps"] == c["untimed_steps_before_clock"] == 40 + c["prime_steps"] + 5
     assert "domain_randomize" in c["terrain_variants"] and "fp32_div_sqrt" not in c          # the product rounds `/` and sqrt correctly: no footnote
     assert len(d["ranks_dt"]) == 1 and 0 < d["ranks_dt"][0] <= d["ms_per_step"] * 1e-3 * 20 * 1.0001
     r = d["roofline"]

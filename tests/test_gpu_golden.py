@@ -91,7 +91,7 @@ def test_observe_kernel_against_reference_step(golden_dir, method, observe, sour
             assert It[abi.I_STEP] == int(k("out_step")) and It[abi.I_STEPS_UNTIL_CMD] == int(k("out_steps_until_next_cmd")), i
             # what the case exercises, counted on the KERNEL's outputs: a command that changed, a gyro row that carries noise
             nchanged += bool(np.abs(St[abi.S_CMD:abi.S_CMD + 3] - S[abi.S_CMD:abi.S_CMD + 3, i]).max() > 1e-3)
-            nnoisy += bool(np.abs(b["obs_state"][i, :3] - F[abi.F_GYRO:abi.F_GYRO + 3, i]).min() > 0.05)
+            nnoisy += bool(np.abs(b["obs_state"][i, :3] - F[abi.F_GYRO:abi.F_GYRO + 3, i]).min() > 0.03)       # |2u - 1| * 0.2 = 0.12 / 0.04 / 0.08
     assert npos >= 2           # the fixtures include un-clipped positive totals
     if source == "draws":      # the point of these records: the stochastic branches are taken, by the kernel, with the reference's numbers
         assert nchanged >= 20 and nnoisy == n, (nchanged, nnoisy)

@@ -834,6 +834,16 @@ def test_variant_label_out_of_range_is_an_error_not_a_fault():
             with pytest.raises(native.PgttError, match="variant label"):
                 env.reset(1)
             assert torch.equal(env.buffers["state"], before)                      # nothing was written
+        # a MASKED reset is the form a caller may keep in its loop: after a check that passed it does not wait for the stream again (labels edited in
+        # place since are clamped, like in the step) - until pgtt_bind / pgtt_set_terrain hand the library new labels, when the next reset of any kind checks
+        env.buffers["variant"][5] = int(good[5]); env.reset(1)
+        env.buffers["variant"][5] = T + 3
+        m = torch.zeros(n, dtype=torch.uint8); m[7] = 1
+        env.reset(1, mask=m)                                                      # no error: asynchronous, label clamped
+        env._bind()
+        with pytest.raises(native.PgttError, match="variant label"):
+            env.reset(1, mask=m)
+        env.buffers["variant"][5] = int(good[5]); env.reset(1, mask=m)
         # stepping with the bad labels in place: clamped to the last / first variant, bit-identical to an env that carries the clamped labels
         env.buffers["variant"][5] = 2 ** 30; env.buffers["variant"][6] = -7
         ref_lab = good.copy(); ref_lab[5] = T - 1; ref_lab[6] = 0
