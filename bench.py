@@ -270,10 +270,11 @@ def profile_record(workload, n):
         return {}, False
     src = allrec.get("_source", {})
     try:
-        # two guards: the sources on disk (a checkout edited since the counters were taken) AND the library this process actually loaded (a stale
-        # libpgtt.so, or PGTT_LIB pointing at a side build made from the same sources with other flags).  An installed package without csrc/ cannot
-        # be checked: withheld as stale rather than costing the headline line.
-        if src.get("csrc_sha256") != native.source_sha256() or src.get("lib_sha256") != native.library_sha256(native.LIB_PATH):
+        # the guard is what the LOADED library says it was built from (pgtt_build_info(): the source hash csrc/Makefile embedded, and the build
+        # flavour - a stale libpgtt.so, or PGTT_LIB pointing at a side build made from the same sources with other flags, is caught; a relink of
+        # the same objects is not mistaken for another kernel).
+        info = native.build_info()
+        if src.get("csrc_sha256") != info.get("src") or info.get("flavor") != "product":
             return {}, True
     except Exception:
         return {}, True

@@ -308,6 +308,9 @@ int pgtt_sizeof_model(void);
 int pgtt_sizeof_config(void);
 int pgtt_sizeof_buffers(void);
 const char* pgtt_version(void);
+/* "src=<SHA-256 of the kernel sources this library was built from>;flavor=<product|fastdiv|flip>": lets a measurement record say which build it
+ * belongs to (bench.py quotes rocprofv3 counters only for the build they were collected on) */
+const char* pgtt_build_info(void);
 const char* pgtt_last_error(void);
 
 #ifdef __cplusplus

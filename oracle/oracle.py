@@ -95,9 +95,10 @@ def _fp(a):
 
 
 def forward(model: abi.PgttModel, qpos, qvel, ctrl, warm=None, boxes=None, box_friction=None, params=None,
-            fp64: bool = True) -> Dict[str, Any]:
-    """One mjx.forward + Euler for a single env; returns every intermediate as float64 arrays."""
-    L = lib()
+            fp64: bool = True, lib: Optional[C.CDLL] = None) -> Dict[str, Any]:
+    """One mjx.forward + Euler for a single env; returns every intermediate as float64 arrays.  `lib`: another build of the checker
+    (tests/parity_explain.py: the -O3 -march=native build as a stand-in device)."""
+    L = lib if lib is not None else globals()["lib"]()
     assert L.pgtt_oracle_sizeof_dump() == C.sizeof(Dump)
     d = Dump()
     warm = np.zeros(18) if warm is None else warm

@@ -14,7 +14,7 @@ _LIB: Optional[C.CDLL] = None
 
 EXPORTS = ["pgtt_create", "pgtt_destroy", "pgtt_set_terrain", "pgtt_bind", "pgtt_reset", "pgtt_step",
            "pgtt_physics", "pgtt_observe", "pgtt_scan", "pgtt_interval_reduce", "pgtt_set_test_overrides", "pgtt_enable_timing", "pgtt_last_kernel_ms", "pgtt_kernel_ms_mean",
-           "pgtt_obs_dims", "pgtt_sizeof_model", "pgtt_sizeof_config", "pgtt_sizeof_buffers", "pgtt_version", "pgtt_last_error"]
+           "pgtt_obs_dims", "pgtt_sizeof_model", "pgtt_sizeof_config", "pgtt_sizeof_buffers", "pgtt_version", "pgtt_build_info", "pgtt_last_error"]
 TRAIN_EXPORTS = ["pgtt_ppo_policy_loss", "pgtt_ppo_linear_backward", "pgtt_policy_act", "pgtt_policy_packed_floats", "pgtt_rollout_record",
                  "pgtt_sizeof_policy_act_args", "pgtt_sizeof_rollout_record_args"]      # include/pgtt_train.h: trainer helpers, not the env boundary
 
@@ -24,25 +24,19 @@ class PgttError(RuntimeError):
 
 
 def source_sha256() -> str:
-    """SHA-256 over the sources physics_kernel is built from - what the translation unit csrc/pgtt_physics_inst.hip includes, plus the Makefile
-    that holds its flags - with comments and white space removed (a comment edit does not change the kernel): tools/collect_profiles.py stores it next to
-    the rocprofv3 counters of that kernel, bench.py compares it before quoting them."""
-    import hashlib
-    import re
-    h = hashlib.sha256()
-    root = os.path.dirname(_HERE)
-    files = sorted([os.path.join(_HERE, "csrc", f) for f in ("pgtt_physics_inst.hip", "pgtt_physics.hip.h", "pgtt_physics_quad.hip.h", "pgtt_kernels.hip.h", "Makefile")]
-                   + [os.path.join(root, "include", "pgtt.h")])
-    for f in files:
-        with open(f, "r") as fh:
-            text = fh.read()
-        if f.endswith("Makefile"):
-            text = "\n".join(ln for ln in text.splitlines() if not ln.lstrip().startswith("#"))
-        else:
-            text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
-            text = re.sub(r"//[^\n]*", " ", text)
-        h.update(os.path.basename(f).encode() + b"\0" + " ".join(text.split()).encode() + b"\0")
-    return h.hexdigest()
+    """SHA-256 over the sources physics_kernel is built from, as they are ON DISK (srchash.py).  csrc/Makefile embeds the same hash in the library
+    at build time (`build_info()`): tools/collect_profiles.py stores it next to the rocprofv3 counters of that kernel, bench.py compares the record
+    with what the LOADED library says about itself before quoting them."""
+    from . import srchash
+    return srchash.source_sha256()
+
+
+def build_info(path: Optional[str] = None) -> dict:
+    """What the library says it was built from: {"src": <source_sha256 at build time>, "flavor": "product" | "fastdiv" | "flip" | ...}
+    (pgtt_build_info(), no GPU needed)."""
+    L = C.CDLL(path or LIB_PATH) if (path or _LIB is None) else _LIB
+    L.pgtt_build_info.restype = C.c_char_p
+    return dict(kv.split("=", 1) for kv in L.pgtt_build_info().decode().split(";"))
 
 
 def library_sha256(path: Optional[str] = None) -> str:

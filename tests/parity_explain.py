@@ -1,0 +1,362 @@
+"""Post-mortem of the env-steps of W on which the device (HIP kernels) and the fp32 oracle end up further apart than the bar - TEST INFRASTRUCTURE
+(imports the oracle; used by tests/test_gpu_parity.py, tests/test_gpu_fullsize.py, tests/test_parity_explain.py and tools/gpu_parity_stats.py).
+
+Until round 5 the parity suite held such env-steps to RATES (twice the measured ones).  Here every one of them is replayed substep by substep
+and has to show one of the two causes DESIGN.md 3 names - or the test fails:
+
+  * `cap`   the reference truncates Newton at `iterations` = 5 (go2/xmls/go2_mjx_feetonly.xml:17).  From the DEVICE's own input to a substep,
+            a* = the minimiser of that substep's convex problem (fp64 oracle, caps lifted to 100 iterations x 60 line-search rounds).  The cause is
+            `cap` when one side's acceleration is off a* (dt |a - a*| > 5e-4 or |a - a*| / (1 + |a*|) > 2e-3: a tenth of the bars) AND that side
+            stopped because it ran out of iterations (niter == iterations); also when the fp64 oracle itself, at the reference's caps, is cut on
+            the device's input (the env-step sits on the edge of W).  A side that is off the minimiser WITHOUT having hit the cap is `unexplained`.
+  * `sign`  the ACTIVE contact sets of the device and of the fp64 oracle differ on the same input, and every pair in the difference has
+            |dist| < SIGN_TOL x max(1, |foot position|): a distance within rounding of 0 changed sides.  A differing pair that is not that close is
+            `unexplained`.
+  * `downstream`  the physics state at the end of the control step is inside the bar (qpos, qvel, warm start, flags, sets) and only derived rows
+            (scan, observations, sensor frame, rewards ...) miss theirs: handled by `explain_downstream`.
+
+The replay runs ONE mjx.step per call on the device (a second handle with ctrl_dt = sim_dt, same lane layout; physics only) and must reproduce the
+bits of the control step it explains - otherwise the verdict is `unexplained: replay`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+
+from oracle import oracle
+from phase_guided_terrain_traversal_amd import abi
+
+SIGN_TOL = 1e-6            # north star: "a contact pair whose oracle |dist| < 1e-6 flips"; scaled by the size of the coordinates it is a difference of
+OFF_DV, OFF_REL = 5e-4, 2e-3
+LONG_ITER, LONG_LS = 100, 60
+EPS32, FLOOR_ULPS = 2.0 ** -24, 8.0
+
+
+def model_copy(ms: abi.PgttModel, **over) -> abi.PgttModel:
+    m = abi.PgttModel.from_buffer_copy(bytes(ms))
+    for k, v in over.items():
+        setattr(m, k, v)
+    return m
+
+
+def active_set(foot, box, dist) -> set:
+    return {(int(f), int(b)) for f, b, d in zip(foot, box, dist) if d < 0 and b != -2}
+
+
+def off_minimiser(a, astar, dt) -> tuple:
+    d = np.abs(np.asarray(a, np.float64) - astar)
+    return float(dt * d.max()), float((d / (1.0 + np.abs(astar))).max())
+
+
+def is_off(dv, rel) -> bool:
+    return dv > OFF_DV or rel > OFF_REL
+
+
+def cost_terms(D: Dict, a) -> tuple:
+    """the convex cost of mjx's solver at acceleration `a` for the problem of dump D (fp64), and the sum of the magnitudes of its terms (what an
+    fp32 evaluation of it is uncertain in proportion to): 1/2 (M a - qfrc_smooth) . (a - qacc_smooth) + 1/2 sum_r D_r min(0, J_r a - aref_r)^2"""
+    a = np.asarray(a, np.float64)
+    J, Dd, aref = D["efc_J"], D["efc_D"], D["efc_aref"]
+    jar = J @ a - aref
+    act = (jar < 0) & (np.asarray(D["efc_active"]) != 0)
+    g = (D["qM"] @ a - D["qfrc_smooth"]) * (a - D["qacc_smooth"])
+    c = 0.5 * Dd * jar * jar * act
+    return float(0.5 * g.sum() + c.sum()), float(0.5 * np.abs(g).sum() + c.sum())
+
+
+class EnvData:
+    """what one env's substeps need besides the state: its terrain variant's boxes, its DR rows"""
+
+    def __init__(self, boxes=None, box_friction=None, params=None):
+        self.boxes, self.box_friction, self.params = boxes, box_friction, params
+
+
+def env_data(hb, terrain, e) -> EnvData:
+    boxes = None if terrain is None else terrain[int(hb["variant"][e]) if "variant" in hb.arrays else 0]
+    bf = hb["box_friction"][:, e].copy() if "box_friction" in hb.arrays and terrain is not None else None
+    pr = hb["params"][:, e].copy() if "params" in hb.arrays else None
+    return EnvData(boxes, bf, pr)
+
+
+def frame_tie(ms, ed: EnvData, inp, ctrl, D32: Dict, D64: Dict) -> str:
+    """contacts whose frame differs between the fp32 and the fp64 oracle on the same input although the sphere centre is within rounding of the
+    SURFACE of the box (|dist + radius| < SIGN_TOL x size of the coordinates): mjx's _sphere_convex takes the normal as normalize(closest point -
+    centre), the direction of a zero-length vector there, and "inside" / "outside" switch formulas - the same kind of event as a contact distance
+    changing sign.  It is an attractor, not a coincidence: a foot sunk into the seam between two stair boxes is pushed onto the seam plane by both.
+    "" if no such contact."""
+    n32, n64 = D32["con_frame"][:, 0], D64["con_frame"][:, 0]
+    scale = max(1.0, float(np.abs(D64["foot_xpos"]).max()))
+    hits = []
+    for c in range(8):
+        if D64["con_box"][c] < 0 or not D64["con_dist"][c] < 0 or float(n32[c] @ n64[c]) >= 0.999:
+            continue
+        r = float(ms.foot_radius[int(D64["con_foot"][c])])
+        if abs(float(D64["con_dist"][c]) + r) < SIGN_TOL * scale or abs(float(D32["con_dist"][c]) + r) < SIGN_TOL * scale:
+            hits.append((int(D64["con_foot"][c]), int(D64["con_box"][c]), float(D64["con_dist"][c]) + r))
+    return "" if not hits else f"(foot, box, centre-to-surface distance) {[(f, b, float(f'{d:.2g}')) for f, b, d in hits]}: the sphere centre lies on the surface of the box, the normal is the direction of a zero-length vector"
+
+
+def judge_substep(ms, ms_long, ed: EnvData, inp, ctrl, sub: Dict, side: str) -> List[Dict]:
+    """one side's substep against the minimiser a* of ITS OWN input (fp64 oracle, caps lifted) and, for the device, against the fp64 oracle's
+    contact set -> list of anomalies {side, substep-less class, dv, rel, detail}"""
+    dt, iters = float(ms.timestep), int(ms.iterations)
+    qpos, qvel, warm = inp
+    kw = dict(boxes=ed.boxes, box_friction=ed.box_friction, params=ed.params)
+    D64 = oracle.forward(ms, qpos, qvel, ctrl, warm, fp64=True, **kw)
+    Dx = oracle.forward(ms_long, qpos, qvel, ctrl, warm, fp64=True, **kw)
+    astar = Dx["qacc"]
+    out = []
+    set64 = active_set(D64["con_foot"], D64["con_box"], D64["con_dist"])
+    con = np.asarray(sub["con"]).reshape(8, 2)
+    sets = active_set(con[:, 0], con[:, 1], sub["dist"])
+    if sets != set64:
+        scale = max(1.0, float(np.abs(D64["foot_xpos"]).max()))
+        worst = 0.0
+        for pair in sets ^ set64:
+            cands = [abs(float(d)) for (f, b), d in zip(con, sub["dist"]) if (int(f), int(b)) == pair]
+            cands += [abs(float(d)) for f, b, d in zip(D64["con_foot"], D64["con_box"], D64["con_dist"]) if (int(f), int(b)) == pair]
+            worst = max(worst, min(cands))
+        ok = worst < SIGN_TOL * scale
+        out.append(dict(side=side, cause="sign" if ok else "unexplained", dv=np.inf, rel=np.inf,
+                        detail=f"{side}: active set differs from the fp64 oracle's on the same input by {sorted(sets ^ set64)}, |dist| {worst:.3g} (tol {SIGN_TOL * scale:.3g})"))
+        return out                 # another constraint set: another problem, its minimiser is not a*
+    o64 = off_minimiser(D64["qacc"], astar, dt)
+    if is_off(*o64):               # the fp64 oracle at the reference's caps is itself cut on this input: the edge of W
+        out.append(dict(side="fp64 oracle", cause="cap" if D64["niter"] >= iters else "unexplained", dv=o64[0], rel=o64[1],
+                        detail=f"fp64 oracle cut at the cap on the {side}'s input (dv {o64[0]:.3g}, rel {o64[1]:.3g}, niter {int(D64['niter'])})"))
+    off = off_minimiser(sub["qacc"], astar, dt)
+    if is_off(*off):
+        ni = int(sub["niter"])
+        c_side, mag = cost_terms(D64, sub["qacc"])
+        c_star, _ = cost_terms(D64, astar)
+        gap = (c_side - c_star) / (EPS32 * mag)
+        cause = "cap" if ni >= iters else ("floor" if gap < FLOOR_ULPS else "unexplained")
+        detail = f"{side} off the minimiser (dv {off[0]:.3g}, rel {off[1]:.3g}) with niter {ni} of {iters}, cost above the minimum by {gap:.3g} fp32 roundings of its terms"
+        if cause == "unexplained":
+            # neither the cut nor the resolution of the cost.  Is it this side's arithmetic, or the fp32 ALGORITHM on this input?  The fp32 oracle on the
+            # same input: if the side lands where it does, the question becomes why fp32 and fp64 differ here - a discrete geometric choice within rounding
+            # of a tie (the face of a box nearest to a sphere centre INSIDE it: mjx _sphere_convex) gives the two precisions different constraint rows
+            D32 = oracle.forward(ms, qpos, qvel, ctrl, warm, fp64=False, **kw)
+            if not is_off(*off_minimiser(sub["qacc"], D32["qacc"], dt)):
+                tie = frame_tie(ms, ed, inp, ctrl, D32, D64)
+                if tie:
+                    cause, detail = "tie", f"{side} = the fp32 oracle on the same input (niter {int(D32['niter'])}); fp32 and fp64 build different contact frames there: {tie}"
+        out.append(dict(side=side, cause=cause, dv=off[0], rel=off[1], gap_ulps=gap, niter=ni, detail=detail))
+    return out
+
+
+def explain_physics(ms: abi.PgttModel, ed: EnvData, x0: np.ndarray, ctrl: np.ndarray, dev: List[Dict], final_dev: Optional[np.ndarray] = None,
+                    orc: Optional[List[Dict]] = None) -> Dict:
+    """x0 = rows [0:55] of the state BEFORE the control step (qpos 19, qvel 18, warm start 18), ctrl = the 12 motor targets, dev = the device's own
+    substeps (dicts with qpos, qvel, qacc, niter, con [8][2], dist [8]), final_dev = rows [0:55] the product's control step ended with, orc = the
+    fp32 oracle's OWN substeps from x0.  EVERY substep of either side is judged on its own input (judge_substep); the verdict is `unexplained` if
+    any anomaly is, else the class of the largest one, else "none": both sides sit on the minimiser of every substep with the fp64 oracle's
+    contact set (the caller decides what that means for a row that still misses its bar)."""
+    ms_long = model_copy(ms, iterations=LONG_ITER, ls_iterations=LONG_LS)
+    if final_dev is not None:
+        last = dev[-1]
+        rep = np.concatenate([last["qpos"], last["qvel"], last["qacc"]]).astype(np.float32)
+        if not np.array_equal(rep, final_dev.astype(np.float32)):
+            return dict(cause="unexplained", substep=-1, side="device", detail=f"replay: one-substep launches do not reproduce the control step (max diff {np.abs(rep - final_dev).max():.3g})")
+    anomalies = []
+    for side, subs in (("device", dev), ("fp32 oracle", orc)):
+        if subs is None:
+            continue
+        inp = (x0[:19].astype(np.float64), x0[19:37].astype(np.float64), x0[37:55].astype(np.float64))
+        for s, sub in enumerate(subs):
+            for an in judge_substep(ms, ms_long, ed, inp, ctrl, sub, side):
+                anomalies.append(dict(an, substep=s))
+            inp = (sub["qpos"].astype(np.float64), sub["qvel"].astype(np.float64), sub["qacc"].astype(np.float64))
+    if not anomalies:
+        return dict(cause="none", substep=-1, side="", detail="both sides sit on the minimiser of every substep, with the fp64 oracle's contact set", trail=[])
+    bad = [an for an in anomalies if an["cause"] == "unexplained"]
+    top = bad[0] if bad else max(anomalies, key=lambda an: (an["dv"], an["rel"]))
+    return dict(cause=top["cause"], substep=top["substep"], side=top["side"], detail=top["detail"], trail=anomalies)
+
+
+def fp32_chain(ms, ed: EnvData, x0: np.ndarray, ctrl: np.ndarray, nsub: int):
+    """the fp32 oracle's control step from rows [0:55] x0, one mjx.step at a time -> (final rows [0:55], active set of the last substep)"""
+    qpos, qvel, warm = x0[:19].astype(np.float64), x0[19:37].astype(np.float64), x0[37:55].astype(np.float64)
+    D = None
+    for _ in range(nsub):
+        D = oracle.forward(ms, qpos, qvel, ctrl, warm, boxes=ed.boxes, box_friction=ed.box_friction, params=ed.params, fp64=False)
+        qpos, qvel, warm = D["qpos_next"], D["qvel_next"], D["qacc"]
+    return np.concatenate([qpos, qvel, warm]), active_set(D["con_foot"], D["con_box"], D["con_dist"])
+
+
+ENSEMBLE, ENSEMBLE_ULPS = 32, 2
+
+
+def rounding_ensemble(ms, ed: EnvData, x0: np.ndarray, ctrl: np.ndarray, nsub: int, dt_ctrl: float, seed: int = 0) -> Dict:
+    """Does the REFERENCE ALGORITHM meet the bar against itself on this env-step?  The fp32 oracle's control step from ENSEMBLE copies of the input whose
+    every component is moved by a random -2 .. +2 fp32 roundings - what a different but equally valid fp32 evaluation of the previous step would have
+    handed over - against its control step from the input itself: largest qpos / qvel / warm-start distance, and whether the active contact set of the
+    last substep changes.  An env-step on which these exceed the bars is one on which the reference's answer depends on rounding by more than the
+    bars allow; no fp32 implementation can be held to them there."""
+    rng = np.random.default_rng(seed)
+    base, set0 = fp32_chain(ms, ed, x0.astype(np.float32), ctrl, nsub)
+    out = dict(qpos=0.0, qvel=0.0, warm=0.0, sets=False)
+    for _ in range(ENSEMBLE):
+        x = x0[:55].astype(np.float32).copy()
+        k = rng.integers(-ENSEMBLE_ULPS, ENSEMBLE_ULPS + 1, size=55)
+        x = (x.astype(np.float64) + k * np.spacing(np.abs(x)).astype(np.float64)).astype(np.float32)
+        fin, st = fp32_chain(ms, ed, x, ctrl, nsub)
+        out["qpos"] = max(out["qpos"], float(np.abs(fin[:19] - base[:19]).max()))
+        out["qvel"] = max(out["qvel"], float(np.abs(fin[19:37] - base[19:37]).max()))
+        out["warm"] = max(out["warm"], float((np.abs(fin[37:55] - base[37:55]) / (1 + np.abs(base[37:55]))).max()))
+        out["sets"] = out["sets"] or st != set0
+    return out
+
+
+def scan_ensemble(cs, ed: EnvData, qpos_orc: np.ndarray, qpos_dev: np.ndarray, seed: int = 0) -> np.ndarray:
+    """the height scan (go2/heightmap.py:10-67) is a STEP function of the pose: a ray within rounding of a box edge lands on the box or beside it.
+    -> per ray, the largest change of the fp32 oracle's own scan height when the pose it is taken from moves by <= ENSEMBLE_ULPS fp32 roundings
+    (and at the device's pose, which differs from the oracle's by no more than the qpos bar)"""
+    rng = np.random.default_rng(seed)
+
+    def scan_at(q):
+        q = np.asarray(q, np.float64)
+        return oracle.scan(cs, ed.boxes, q[:3], oracle.quat_to_yaw(q[3:7], fp64=False), fp64=False)[:, :, 2].reshape(-1)
+    base = scan_at(qpos_orc.astype(np.float32))
+    spread = np.abs(scan_at(qpos_dev.astype(np.float32)) - base)
+    for _ in range(ENSEMBLE):
+        q = qpos_orc[:7].astype(np.float32)
+        k = rng.integers(-ENSEMBLE_ULPS, ENSEMBLE_ULPS + 1, size=7)
+        spread = np.maximum(spread, np.abs(scan_at((q.astype(np.float64) + k * np.spacing(np.abs(q)).astype(np.float64)).astype(np.float32)) - base))
+    return spread
+
+
+# ---------------------------------------------------------------------------------------------------------------- providers of the device's substeps
+class DeviceSubsteps:
+    """the HIP kernels, one mjx.step per launch: a second handle with ctrl_dt = sim_dt (n_substeps = 1) on the SAME lane layout and the SAME batch,
+    physics only.  The whole batch is replayed, not the envs in question alone: the oct and hex layouts split a wave's contact work by the number
+    of box slots in use ANYWHERE in the wave, so an env's roundings depend on the company it keeps in its wave (bit-identity holds for a fixed
+    grouping of envs into waves - shards that start at a multiple of 16 envs - which is what DESIGN.md 4 / 7 claim)."""
+
+    def __init__(self, task, cfg, model, terrain, layout, n, opt: Dict[str, np.ndarray]):
+        import torch
+        from phase_guided_terrain_traversal_amd.env import Joystick
+        cfg = dict(cfg)
+        cfg["ctrl_dt"] = cfg["sim_dt"]
+        kw = {kk: torch.from_numpy(np.ascontiguousarray(v)) for kk, v in opt.items()}
+        self.env = Joystick(task, cfg, num_envs=n, terrain=terrain, device="cuda:0", debug_contacts=True, layout=layout, model=model, **kw)
+
+    def __call__(self, cols: np.ndarray, S0: np.ndarray, act: np.ndarray, ctrl: np.ndarray, nsub: int) -> List[List[Dict]]:
+        import torch
+        env = self.env
+        env.buffers["state"].copy_(torch.from_numpy(np.ascontiguousarray(S0)))
+        a = torch.from_numpy(np.ascontiguousarray(act)).cuda()
+        out = [[] for _ in cols]
+        for _ in range(nsub):
+            env.physics(a)
+            torch.cuda.synchronize()
+            st = env.buffers["state"][:55].cpu().numpy()
+            con, dist, ni = env.buffers["dbg_contact"].cpu().numpy(), env.buffers["dbg_dist"].cpu().numpy(), env.buffers["dbg_niter"].cpu().numpy() & 0xFFFF
+            for i, e in enumerate(cols):
+                out[i].append(dict(qpos=st[:19, e].copy(), qvel=st[19:37, e].copy(), qacc=st[37:55, e].copy(), niter=int(ni[e]), con=con[e].copy(), dist=dist[e].copy()))
+        return out
+
+    def close(self):
+        self.env.close()
+
+
+class OracleSubsteps:
+    """CPU stand-in for the device (tests/test_parity_explain.py): another fp32 build of the oracle (-O3 -march=native: FMA contraction, other
+    vectorisation), one mjx.forward + Euler per substep"""
+
+    def __init__(self, libpath: Optional[str], ms: abi.PgttModel, get_env_data: Callable[[int], EnvData]):
+        self.L = C.CDLL(libpath) if libpath else None
+        self.ms, self.get = ms, get_env_data
+
+    def __call__(self, cols, S0, act, ctrl, nsub):
+        out = []
+        for e in cols:
+            e = int(e)
+            ed = self.get(e)
+            qpos, qvel, warm = (S0[:19, e].astype(np.float64), S0[19:37, e].astype(np.float64), S0[37:55, e].astype(np.float64))
+            subs = []
+            for _ in range(nsub):
+                D = oracle.forward(self.ms, qpos, qvel, ctrl[:, e].astype(np.float64), warm, boxes=ed.boxes, box_friction=ed.box_friction, params=ed.params, fp64=False, lib=self.L)
+                con = np.stack([D["con_foot"], D["con_box"]], 1)
+                subs.append(dict(qpos=D["qpos_next"].astype(np.float32), qvel=D["qvel_next"].astype(np.float32), qacc=D["qacc"].astype(np.float32),
+                                 niter=int(D["niter"]), con=con, dist=D["con_dist"].astype(np.float32)))
+                qpos, qvel, warm = D["qpos_next"], D["qvel_next"], D["qacc"]
+            out.append(subs)
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- the per-step driver
+PHYS_KEYS = ("qpos", "qvel", "warm")
+
+
+class Ledger:
+    """collects the violations of one run_parity call and their verdicts"""
+
+    def __init__(self):
+        self.records: List[Dict] = []
+
+    def add(self, **rec):
+        self.records.append(rec)
+
+    def count(self, cause):
+        return sum(1 for r in self.records if r["cause"] == cause)
+
+    def summary(self) -> Dict:
+        out = {c: self.count(c) for c in ("cap", "floor", "sign", "tie", "unstable", "edge", "unexplained")}
+        out["violations"] = len(self.records)
+        out["cap_side"] = {side: sum(1 for r in self.records if r["cause"] == "cap" and r.get("side") == side) for side in ("device", "fp32 oracle", "fp64 oracle")}
+        return out
+
+    def unexplained(self) -> List[Dict]:
+        return [r for r in self.records if r["cause"] == "unexplained"]
+
+
+def explain_step(ledger: Ledger, k: int, viol_envs: np.ndarray, viol_keys: Dict[int, List[str]], ms, hb, terrain, S0: np.ndarray, act: np.ndarray,
+                 ctrl_rows: np.ndarray, final_dev_rows: np.ndarray, substeps: Callable, nsub: int,
+                 skip_final_check: Optional[np.ndarray] = None, observed: Optional[Dict[str, np.ndarray]] = None, scan_ctx: Optional[Dict] = None) -> None:
+    """one control step: `viol_envs` = envs of W that miss some bar, `viol_keys[e]` = which; S0 = the state rows before the step (all envs),
+    ctrl_rows = the 12 motor-target rows, final_dev_rows = the device's state rows [0:55] after the step, observed = the per-env errors the bars were
+    applied to (per_env_errors of the caller), scan_ctx = {cs, dev_scan [N][117], orc_scan [N][117]} for the `edge` class"""
+    if len(viol_envs) == 0:
+        return
+    dev = substeps(viol_envs, S0, act, ctrl_rows, nsub)
+    orc = OracleSubsteps(None, ms, lambda e: env_data(hb, terrain, e))(viol_envs, S0, act, ctrl_rows, nsub)
+    for i, e in enumerate(viol_envs):
+        e = int(e)
+        keys = viol_keys[e]
+        last = orc[i][-1]
+        skip = skip_final_check is not None and bool(skip_final_check[e])
+        if not skip and not np.array_equal(np.concatenate([last["qpos"], last["qvel"], last["qacc"]]), hb["state"][:55, e]):
+            ledger.add(step=k, env=e, keys=keys, cause="unexplained", substep=-1, side="fp32 oracle", detail="replay: the oracle's one-substep calls do not reproduce its own control step", trail=None)
+            continue
+        ed = env_data(hb, terrain, e)
+        v = explain_physics(ms, ed, S0[:55, e], ctrl_rows[:, e].astype(np.float64), dev[i], None if skip else final_dev_rows[:, e], orc[i])
+        if v["cause"] == "none" and "scan" in keys and scan_ctx is not None and not skip and not [kk for kk in keys if kk in PHYS_KEYS]:
+            # physics identical to rounding on both sides; the scan differs: a ray on the edge of a box?
+            spread = scan_ensemble(scan_ctx["cs"], ed, hb["state"][:19, e], final_dev_rows[:19, e], seed=1000 * k + e)
+            diff = np.abs(scan_ctx["dev_scan"][e] - scan_ctx["orc_scan"][e])
+            rays = np.nonzero(diff > 1e-5)[0]
+            if len(rays) and all(spread[r] >= 0.5 * diff[r] for r in rays):
+                v = dict(v, cause="edge", detail=f"rays {rays.tolist()} differ by up to {diff.max():.3g}; the fp32 oracle's own scan moves by {spread[rays].max():.3g} there when the pose moves by <= {ENSEMBLE_ULPS} roundings: rays on the edge of a box")
+            else:
+                v = dict(v, cause="unexplained", detail=f"scan rays {rays.tolist()} differ by {diff[rays].tolist()} while the oracle's scan under pose rounding moves by {spread[rays].tolist()}")
+        elif v["cause"] in ("unexplained", "none") and not v["detail"].startswith("replay"):
+            # no specific cause: does the reference algorithm itself meet the bar on this env-step when its input moves by fp32 roundings?
+            ens = rounding_ensemble(ms, ed, S0[:55, e], ctrl_rows[:, e].astype(np.float64), nsub, nsub * float(ms.timestep), seed=1000 * k + e)
+            bars = dict(qpos=1e-4, qvel=1e-4 / (nsub * float(ms.timestep)), warm=1e-2)
+            # a row counts as moved when the reference's own spread under input rounding is over the bar, or at least half of what the device differs by
+            moved = lambda kk: ens[kk] > bars[kk] or (observed is not None and ens[kk] >= 0.5 * float(observed[kk][e]) and float(observed[kk][e]) > bars[kk])
+            over = [kk for kk in PHYS_KEYS if moved(kk)] + (["sets"] if ens["sets"] else [])
+            need = [kk for kk in keys if kk in PHYS_KEYS]
+            # a physics row that misses its bar must be one the ensemble moves too; rows derived from the physics (sensor frame, observations,
+            # rewards, contact flags ...) follow whichever physics row moves
+            ok = all(kk in over for kk in need) if need else bool(over)
+            first = v["detail"]
+            tail = f"qpos {ens['qpos']:.2g}, qvel {ens['qvel']:.2g}, warm {ens['warm']:.2g}, active set changes: {ens['sets']}"
+            if ok:
+                v = dict(v, cause="unstable", detail=f"the fp32 oracle misses the bar against ITSELF when its input moves by <= {ENSEMBLE_ULPS} roundings ({tail}) [{first}]")
+            else:
+                v = dict(v, cause="unexplained", detail=f"{first}; the fp32 oracle under input rounding: {tail}")
+        ledger.add(step=k, env=e, keys=keys, **{kk: vv for kk, vv in v.items() if kk != "trail"}, trail=v.get("trail"))

@@ -40,7 +40,9 @@ def test_driver_command_line_contract():
     # counters are quoted only when profiles/hbm_traffic.json was measured on the sources of the library being timed
     from phase_guided_terrain_traversal_amd import native
     measured_on = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get("_source", {}).get("csrc_sha256")
-    assert r["profile_stale"] is (measured_on != native.source_sha256())
+    info = native.build_info()
+    assert info["flavor"] == "product" and info["src"] == native.source_sha256()            # the loaded library is the product build of this tree
+    assert r["profile_stale"] is (measured_on != info["src"])
     if r["profile_stale"]:
         assert r["traffic"] is None and r["valu_busy"] is None and r["mfma_ops"] is None
     else:

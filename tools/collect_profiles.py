@@ -58,7 +58,9 @@ for T, key in (("flat", "flat_4096"), ("wfc_dr_8192", "wfc_dr_8192"), ("level4_u
 # which kernel sources these counters belong to: bench.py withholds them ("profile_stale": true) when the library it times was built from others
 sys.path.insert(0, root)
 from phase_guided_terrain_traversal_amd import native
-t["_source"] = {"csrc_sha256": native.source_sha256(), "lib_sha256": native.library_sha256() if os.path.exists(native.LIB_PATH) else None, "tag": tag,
-                "what": "SHA-256 over the sources of physics_kernel (csrc/pgtt_physics_inst.hip and the headers it includes, csrc/Makefile, include/pgtt.h: native.source_sha256) at the time the counters were collected; lib_sha256 = libpgtt.so itself"}
+info = native.build_info()
+assert info["flavor"] == "product" and info["src"] == native.source_sha256(), "libpgtt.so is not the product build of the sources on disk: rebuild before collecting"
+t["_source"] = {"csrc_sha256": info["src"], "flavor": info["flavor"], "lib_sha256": native.library_sha256(), "tag": tag,
+                "what": "pgtt_build_info() of the libpgtt.so the counters were collected on: SHA-256 over the sources of physics_kernel (csrc/pgtt_physics_inst.hip and the headers it includes, csrc/Makefile, include/pgtt.h: srchash.py) embedded at build time; lib_sha256 = the file itself (informational)"}
 json.dump(t, open(tp, "w"), indent=1)
 print("collected", tag, {k: (round(v["physics_bytes_per_launch"] / 1e6, 2), round(v.get("valu_busy", 0), 3)) for k, v in t.items() if not k.startswith("_")})

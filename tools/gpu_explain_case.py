@@ -1,0 +1,46 @@
+"""Replay ONE saved batch of gpurun_out/unexplained/*.npz (written by tests/test_gpu_parity.py::run_parity when the post-mortem of an env-step of W
+finds no cause) on the device, substep by substep, and print both sides against the minimiser of every substep.
+    python tools/gpu_explain_case.py case.npz [layout]        (GPU box; PGTT_LIB may name another build)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import parity_explain as X
+from oracle import oracle
+from phase_guided_terrain_traversal_amd import abi, configs, mjcf
+
+z = np.load(sys.argv[1], allow_pickle=False)
+layout = sys.argv[2] if len(sys.argv) > 2 else str(z["layout"])
+task, n, nsub, method = str(z["task"]), int(z["n"]), int(z["nsub"]), str(z["method"])
+terrain = z["terrain"] if "terrain" in z.files else None
+import pickle
+model = pickle.loads(z["model_pickle"].tobytes()) if "model_pickle" in z.files else mjcf.load_model(task)
+cfg = pickle.loads(z["cfg_pickle"].tobytes()) if "cfg_pickle" in z.files else configs.training_config(method)
+ms = abi.model_struct(model)
+opt = {k: z[k] for k in ("params", "variant", "box_friction") if k in z.files}
+dev = X.DeviceSubsteps(task, cfg, model, terrain, layout, n, opt)
+S0, act, orc_state = z["S0"], z["act"], z["oracle_state"]
+ctrl = orc_state[abi.S_MOTOR_TARGETS:abi.S_MOTOR_TARGETS + 12]
+envs = [int(e) for e in z["envs"]]
+subs = dev(np.array(envs), S0, act, ctrl, nsub)
+np.set_printoptions(precision=6, linewidth=220, suppress=True)
+ml = X.model_copy(ms, iterations=X.LONG_ITER, ls_iterations=X.LONG_LS)
+out = {}
+for i, e in enumerate(envs):
+    hb = {"variant": opt.get("variant")}
+    boxes = None if terrain is None else terrain[int(opt["variant"][e]) if "variant" in opt else 0]
+    kw = dict(boxes=boxes, box_friction=opt["box_friction"][:, e] if "box_friction" in opt else None, params=opt["params"][:, e] if "params" in opt else None)
+    inp = (S0[:19, e].astype(float), S0[19:37, e].astype(float), S0[37:55, e].astype(float))
+    print(f"env {e} layout {layout} lib {os.environ.get('PGTT_LIB', 'product')}")
+    for s, sub in enumerate(subs[i]):
+        Dx = oracle.forward(ml, *inp[:2], ctrl[:, e].astype(float), inp[2], fp64=True, **kw)
+        D32 = oracle.forward(ms, *inp[:2], ctrl[:, e].astype(float), inp[2], fp64=False, **kw)
+        con = sub["con"].reshape(8, 2)
+        print(f"  substep {s}: device niter {sub['niter']} off {X.off_minimiser(sub['qacc'], Dx['qacc'], 0.005)} | fp32 oracle on the same input niter {D32['niter']} off {X.off_minimiser(D32['qacc'], Dx['qacc'], 0.005)}")
+        print("     device contacts", [(int(f), int(b), round(float(d), 6)) for (f, b), d in zip(con, sub["dist"]) if b != -2])
+        print("     oracle contacts", [(int(f), int(b), round(float(d), 6)) for f, b, d in zip(D32["con_foot"], D32["con_box"], D32["con_dist"]) if b != -2])
+        print("     qacc device", sub["qacc"]); print("     qacc a*    ", Dx["qacc"])
+        out[f"e{e}_s{s}_qacc"] = sub["qacc"]; out[f"e{e}_s{s}_qpos"] = sub["qpos"]; out[f"e{e}_s{s}_qvel"] = sub["qvel"]
+        inp = (sub["qpos"].astype(float), sub["qvel"].astype(float), sub["qacc"].astype(float))
+os.makedirs(os.path.join(ROOT, "gpurun_out", "unexplained"), exist_ok=True)
+np.savez(os.path.join(ROOT, "gpurun_out", "unexplained", os.path.basename(sys.argv[1]).replace(".npz", f"_dev_{layout}.npz")), **out)
