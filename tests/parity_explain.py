@@ -210,6 +210,27 @@ def rounding_ensemble(ms, ed: EnvData, x0: np.ndarray, ctrl: np.ndarray, nsub: i
     return out
 
 
+def reset_ensemble(ms, ed: EnvData, qpos: np.ndarray, qvel: np.ndarray, key_z: float, seed: int = 0) -> float:
+    """Joystick.reset's two forward passes (go2/joystick_pgtt.py:72,78: at the drawn pose, then lifted by the highest scan point, the second warm-started
+    by the first) in the fp32 oracle from ENSEMBLE copies of the pose moved by <= ENSEMBLE_ULPS roundings -> largest relative change of qacc against
+    the unperturbed chain: is the reset's solve one whose answer depends on rounding?"""
+    rng = np.random.default_rng(seed)
+    kw = dict(boxes=ed.boxes, box_friction=ed.box_friction, params=ed.params)
+
+    def chain(qp, qv):
+        q0 = qp.astype(np.float64).copy(); q0[2] = key_z
+        D1 = oracle.forward(ms, q0, qv.astype(np.float64), q0[7:], np.zeros(18), fp64=False, **kw)
+        return oracle.forward(ms, qp.astype(np.float64), qv.astype(np.float64), q0[7:], D1["qacc"], fp64=False, **kw)["qacc"]
+    qp, qv = qpos.astype(np.float32), qvel.astype(np.float32)
+    base, spread = chain(qp, qv), 0.0
+    for _ in range(ENSEMBLE):
+        k1, k2 = rng.integers(-ENSEMBLE_ULPS, ENSEMBLE_ULPS + 1, size=19), rng.integers(-ENSEMBLE_ULPS, ENSEMBLE_ULPS + 1, size=18)
+        a = chain((qp.astype(np.float64) + k1 * np.spacing(np.abs(qp)).astype(np.float64)).astype(np.float32),
+                  (qv.astype(np.float64) + k2 * np.spacing(np.abs(qv)).astype(np.float64)).astype(np.float32))
+        spread = max(spread, float((np.abs(a - base) / (1 + np.abs(base))).max()))
+    return spread
+
+
 def scan_ensemble(cs, ed: EnvData, qpos_orc: np.ndarray, qpos_dev: np.ndarray, seed: int = 0) -> np.ndarray:
     """the height scan (go2/heightmap.py:10-67) is a STEP function of the pose: a ray within rounding of a box edge lands on the box or beside it.
     -> per ray, the largest change of the fp32 oracle's own scan height when the pose it is taken from moves by <= ENSEMBLE_ULPS fp32 roundings

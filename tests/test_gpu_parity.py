@@ -149,16 +149,38 @@ def run_parity(task, n, terrain, steps, dr=False, autoreset=False, noise=1.0, me
     # Round 5 (correctly rounded division / sqrt in the product): 1 env of 128 on level13 + DR sits at 3.1e-2 on its warm start with 2 Newton iterations
     # on both sides and identical contacts (|qacc| ~ 270 in that reset, tools/gpu_reset_warm_diag.py): the tail of a rounding error, so ONE env may miss the
     # bar in a small batch as 0.1 % may in a big one - but none by more than 5 x
+    # Round 6: no blanket allowance.  An env that misses one of these bars must be one whose reset solve depends on rounding IN THE
+    # ORACLE ITSELF: the fp32 oracle's two forward passes from its pose moved by <= 2 roundings change qacc (relative) by at least half of what the
+    # device differs by (parity_explain.reset_ensemble; round 5's case, |qacc| ~ 270 with 2 iterations on both sides and equal contacts, is one).
+    # Second line: never more than max(1, 0.1 %) of the envs, none by more than 5 x.
+    key_z = float(np.asarray(env.model["key_qpos"])[2])
+    reset_spread = {}
+
+    def spread_of(e):
+        if e not in reset_spread:
+            reset_spread[e] = X.reset_ensemble(ms, X.env_data(hb, terrain, e), hb["state"][:19, e], hb["state"][19:37, e], key_z, seed=e)
+        return reset_spread[e]
+    ci = np.nonzero(conv0)[0]
     few = lambda per_env, tol: (per_env > tol).sum() <= max(1, 1e-3 * n) and not (per_env > 5 * tol).any()
-    assert few((np.abs(g["state"][37:55] - hb["state"][37:55]) / (1 + np.abs(hb["state"][37:55])))[:, conv0].max(0), 2e-2)
+    warm0 = (np.abs(g["state"][37:55] - hb["state"][37:55]) / (1 + np.abs(hb["state"][37:55])))[:, conv0].max(0)
+    assert few(warm0, 2e-2)
+    for j in np.nonzero(warm0 > 2e-2)[0]:
+        assert spread_of(int(ci[j])) >= 0.5 * warm0[j], (int(ci[j]), float(warm0[j]), reset_spread)
     assert np.abs(g["state"][55:] - hb["state"][55:]).max() < 1e-5
-    # the privileged observation holds the accelerometer and actuator forces of the reset's forward pass: compared where
-    # that solve converged on both sides (same reason as in the step loop below)
-    assert few(np.abs(g["obs_priv"] - hb["obs_priv"])[conv0].max(1), 5e-3)
+    # the privileged observation holds the accelerometer and actuator forces of the reset's forward pass: compared where that solve converged on
+    # both sides (same reason as in the step loop below); an accelerometer row moves by about (1 + |qacc|) x the relative change of qacc
+    qs = 1.0 + np.abs(hb["state"][37:55]).max(0)
+    priverr = np.abs(g["obs_priv"] - hb["obs_priv"])[conv0].max(1)
+    assert few(priverr, 5e-3)
+    for j in np.nonzero(priverr > 5e-3)[0]:
+        assert spread_of(int(ci[j])) * qs[ci[j]] >= 0.5 * priverr[j], (int(ci[j]), float(priverr[j]), reset_spread, float(qs[ci[j]]))
     assert np.abs(g["obs_state"] - hb["obs_state"]).max() < 5e-3
     assert np.array_equal(g["istate"], hb["istate"])
     assert np.array_equal(g["frame"][abi.F_CONTACT:abi.F_CONTACT + 4], hb["frame"][abi.F_CONTACT:abi.F_CONTACT + 4])
-    assert few(np.abs(g["first_obs"] - hb["first_obs"])[conv0].max(1), 5e-3)            # [N][171 + 215]
+    foerr = np.abs(g["first_obs"] - hb["first_obs"])[conv0].max(1)            # [N][171 + 215]: the same two rows once more
+    assert few(foerr, 5e-3) and set(ci[foerr > 5e-3]) <= set(ci[priverr > 5e-3])
+    if reset_spread:
+        print("reset: envs over a bar and the fp32 oracle's own qacc spread under <= 2 roundings of the pose:", {e: f"{v:.3g}" for e, v in reset_spread.items()})
     rng = np.random.default_rng(1)
     EG, EF, flag_mismatch, set_mismatch, nactive, nbox_active = [], [], 0, 0, 0, 0
     nviol = {}
