@@ -257,16 +257,22 @@ PG_INL void qarrow_mul(const QArrow& A, const float* xb, const float* xl, float*
     yl[k] = s;
   }
 }
+// -DPGTT_EXACT_PIVOT side builds (profiles/r06_rsq_ab.txt): the inverse pivots from a correctly rounded square root and a correctly rounded division
+#ifdef PGTT_EXACT_PIVOT
+#define PG_RSQ(x) (1.0f / sqrtf(x))
+#else
+#define PG_RSQ(x) __builtin_amdgcn_rsqf(x)
+#endif
 PG_INL void qarrow_factor(QArrow& A) {
   float* c = A.ll;
   // The diagonal of a Cholesky factor is only ever used as a divisor (here and in qarrow_solve), so the factor keeps its
   // INVERSE: one v_rsq_f32 (1 ulp) per pivot and multiplications instead of a square root plus ~40 divisions (8
   // instructions each in the 1-ulp form) per factorisation + solve.
-  const float i00 = __builtin_amdgcn_rsqf(c[0]);
+  const float i00 = PG_RSQ(c[0]);
   float l10 = c[1] * i00, l20 = c[3] * i00;
-  const float i11 = __builtin_amdgcn_rsqf(c[2] - l10 * l10);
+  const float i11 = PG_RSQ(c[2] - l10 * l10);
   float l21 = (c[4] - l20 * l10) * i11;
-  const float i22 = __builtin_amdgcn_rsqf(c[5] - l20 * l20 - l21 * l21);
+  const float i22 = PG_RSQ(c[5] - l20 * l20 - l21 * l21);
   c[0] = i00; c[1] = l10; c[2] = i11; c[3] = l20; c[4] = l21; c[5] = i22;
   float* w = A.lb;
   if (kSubs != 4) {
@@ -327,7 +333,7 @@ PG_INL void qarrow_factor(QArrow& A) {
     float s = A.bb[tri(j, j)];
 #pragma unroll
     for (int k = 0; k < j; k++) s -= A.bb[tri(j, k)] * A.bb[tri(j, k)];
-    const float id = __builtin_amdgcn_rsqf(s);
+    const float id = PG_RSQ(s);
     A.bb[tri(j, j)] = id;
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {

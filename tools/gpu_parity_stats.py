@@ -75,9 +75,11 @@ def ratios(lay="hex"):
     A = os.path.join(ROOT, "phase_guided_terrain_traversal_amd", "assets", "terrains")
     P.EXEC["layout"] = lay
     print("build:", os.path.basename(native.LIB_PATH), "layout", lay)
-    for name, args in (("flat", ("flat_terrain", 512, None, 60)), ("level4", ("stairs", 512, np.load(os.path.join(A, "level4.npy")), 60))):
+    nenv = int(os.environ.get("PGTT_STATS_ENVS", "512"))
+    for name, args in (("flat", ("flat_terrain", nenv, None, 60)), ("level4", ("stairs", nenv, np.load(os.path.join(A, "level4.npy")), 60))):
         eg, ef, ni, fm, sm, rs = collect(*args)
         W = (rs[1] < 1e-6) & (ef["qpos"] < 1e-5) & (ef["qvel"] < 1e-3)
+        print(f"  {name:7s} W = {W.mean():.3%} of {W.size} env-steps; on W: qpos > 1e-4 on {(eg['qpos'][W] > 1e-4).mean():.4%}, qvel > 5e-3 on {(eg['qvel'][W] > 5e-3).mean():.4%}, warm > 1e-2 on {(eg['warm'][W] > 1e-2).mean():.4%}, flags {int((fm & W).sum())}, sets {int((sm & W).sum())}")
         for key in ("qpos", "qvel", "obs", "frame"):
             for tag, f in (("all", np.ones_like(W)), ("W", W)):
                 g, o = np.percentile(eg[key][f], [50, 90, 99, 99.9]), np.percentile(ef[key][f], [50, 90, 99, 99.9])
