@@ -55,6 +55,7 @@ ALGO_FLOP_OBSERVE = 0.35e6              # 117 rays x 101 geoms x ~30 (+ < 0.01 M
 ALGO_BYTES_PHYSICS = 4 * (67 + 132)
 ALGO_BYTES_PHYSICS_DR = ALGO_BYTES_PHYSICS + 4 * 77
 PEAK_FP32_TFLOPS = 157.3                # MI355X fp32 vector peak (MI355X_MICROARCH.md); the fp32 matrix peak is the same number
+PEAK_FP32_UNPACKED_TFLOPS = 78.65      # the same vector ALUs issuing UNPACKED fp32 FMAs (one per lane per cycle): the ceiling of an instruction stream without v_pk_*
 PEAK_HBM_GBS = 8000.0
 CURRICULUM = [1, 2, 3, 4, 7, 10, 13]    # the level files the reference ships (terrains/level*.npy), easiest first
 REDUCE_EVERY = 20                       # log interval of the metric all-reduce (unroll length of training/train.py:142)
@@ -281,6 +282,16 @@ def profile_record(workload, n):
     return rec, False
 
 
+def isa_static():
+    """static instruction mix of the headline kernel (profiles/isa_static.json, tools/isa_static.py), quoted only for the build it was counted on"""
+    from phase_guided_terrain_traversal_amd import native
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "isa_static.json")))
+        return d if d.get("csrc_sha256") == native.build_info().get("src") else {}
+    except Exception:
+        return {}
+
+
 def rooflines(w, workload, n, dr, ms_per_step):
     """`roofline` (dominant kernel = physics_kernel, its OWN share of the algorithmic work), `roofline_observe`, `roofline_step`
     (whole step over the wall time per step) and `roofline_hbm`.  Flops are the dense-MJX count of SURVEY 8d - the arithmetic of the
@@ -295,13 +306,19 @@ def rooflines(w, workload, n, dr, ms_per_step):
     def line(bound, work, ms, peak, unit, scale, **extra):
         a = work / (ms * 1e-3) / scale
         return dict({"bound": bound, "achieved": a, "peak": peak, "unit": unit, "frac": a / peak}, **extra)
+    isa = isa_static() if (workload, n, dr) == ("level4", 4096, False) else {}
     return {
         "roofline": line("valu_fp32", pf, w["physics_ms"], PEAK_FP32_TFLOPS, "TFLOP/s", 1e12, traffic=traffic, kernel="physics_kernel",
                          algorithmic_flop_per_env_step=ALGO_FLOP_PHYSICS, algorithmic_bytes_per_launch=pb,
                          traffic_over_algorithmic=(traffic / pb if traffic else None), valu_busy=rec.get("valu_busy"), mfma_ops=rec.get("mfma_ops"),
                          profile_stale=stale,
+                         # the stated peak assumes packed fp32 (v_pk_fma_f32: two FMAs per lane per issue); this kernel's stream is almost all unpacked
+                         # (-fno-slp-vectorize: pairing the scalar chains costs more registers than it saves issues), so the unpacked ceiling is the fairer one
+                         frac_unpacked_ceiling=pf / (w["physics_ms"] * 1e-3) / 1e12 / PEAK_FP32_UNPACKED_TFLOPS, peak_unpacked=PEAK_FP32_UNPACKED_TFLOPS,
+                         valu_packed_share=isa.get("valu_packed_share"),
                          note="FP32 vector-ALU issue / latency bound (SURVEY 8d): physics share of the dense-MJX count, 4 x 0.30 MFLOP per env-step; "
-                              "MFMA deliberately unused (DESIGN 5.1); valu_busy = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES from profiles/"),
+                              "MFMA deliberately unused (DESIGN 5.1); valu_busy = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES from profiles/; valu_packed_share = "
+                              "static share of v_pk_* among the kernel's vector-ALU instructions (profiles/isa_static.json)"),
         "roofline_observe": line("valu_fp32", of, w["observe_ms"], PEAK_FP32_TFLOPS, "TFLOP/s", 1e12, kernel="observe_kernel",
                                  algorithmic_flop_per_env_step=ALGO_FLOP_OBSERVE),
         "roofline_step": line("valu_fp32", ALGO_FLOP_PER_ENV_STEP * n, ms_per_step, PEAK_FP32_TFLOPS, "TFLOP/s", 1e12,

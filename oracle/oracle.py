@@ -165,10 +165,13 @@ def reset(cfg, model, terrain, bufs: HostBuffers, seed: int, env_id_offset: int 
                             C.c_int64(env_id_offset), m, int(fp64), int(nthreads))
 
 
-def step(cfg, model, terrain, bufs: HostBuffers, action, seed: int, env_id_offset: int = 0, fp64=False, nthreads=1, resid=None):
+def step(cfg, model, terrain, bufs: HostBuffers, action, seed: int, env_id_offset: int = 0, fp64=False, nthreads=1, resid=None, flags=None, fresh_rbound=False):
     """`resid`: optional float64 [N] array receiving, per env, the largest scaled gradient norm at the Newton solver's exit
-    over the substeps (how far from the minimiser the 5-iteration cut left the solve)"""
+    over the substeps (how far from the minimiser the 5-iteration cut left the solve); `flags`: optional int32 [N] receiving OData.diag_flags;
+    `fresh_rbound`: diagnostic switch of the max_geom_pairs ranking (physics_impl.h broad_phase)"""
     lib().pgtt_oracle_set_diag(None if resid is None else resid.ctypes.data_as(C.c_void_p))
+    lib().pgtt_oracle_set_diag_flags(None if flags is None else flags.ctypes.data_as(C.c_void_p))
+    lib().pgtt_oracle_set_fresh_rbound(int(fresh_rbound))
     T, B = (0, 0) if terrain is None else terrain.shape[:2]
     t = None if terrain is None else np.ascontiguousarray(terrain, dtype=np.float32)
     a = np.ascontiguousarray(action, dtype=np.float32)
@@ -176,4 +179,4 @@ def step(cfg, model, terrain, bufs: HostBuffers, action, seed: int, env_id_offse
     s = bufs.struct()
     lib().pgtt_oracle_step(C.byref(cfg), C.byref(model), _fp(t), T, B, bufs.n, C.byref(s), _fp(a), C.c_uint64(seed),
                            C.c_int64(env_id_offset), int(fp64), int(nthreads))
-    lib().pgtt_oracle_set_diag(None)
+    lib().pgtt_oracle_set_diag(None); lib().pgtt_oracle_set_diag_flags(None); lib().pgtt_oracle_set_fresh_rbound(0)

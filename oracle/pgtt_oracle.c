@@ -11,6 +11,9 @@
 double* g_oracle_trace = 0; int g_oracle_trace_n = 0;
 void pgtt_oracle_set_trace(double* buf4000_or_null) { g_oracle_trace = buf4000_or_null; g_oracle_trace_n = 0; }
 int pgtt_oracle_trace_len(void) { return g_oracle_trace_n; }
+/* diagnostic switch (tools/gpu_model_switch_relevance.py only): rank the max_geom_pairs cut with every box's own bounding radius instead of the stale compiled one */
+int g_oracle_fresh_rbound = 0;
+void pgtt_oracle_set_fresh_rbound(int on) { g_oracle_fresh_rbound = on; }
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -232,6 +235,8 @@ typedef struct PgttOraclePostIn {
    solver's exit over its substeps into g_diag_resid[e] */
 static double* g_diag_resid = NULL;
 void pgtt_oracle_set_diag(double* resid_N_or_null) { g_diag_resid = resid_N_or_null; }
+static int32_t* g_diag_flags = NULL;      /* per env: OData.diag_flags of the step (physics_impl.h) */
+void pgtt_oracle_set_diag_flags(int32_t* flags_N_or_null) { g_diag_flags = flags_N_or_null; }
 
 /* ================================================================ batch drivers over the PgttBuffers SoA layout (HOST pointers) */
 #define BATCH(SUF, RT)                                                                                                   \
@@ -338,6 +343,7 @@ void pgtt_oracle_set_diag(double* resid_N_or_null) { g_diag_resid = resid_N_or_n
       task_step_##SUF(&c, d, &in, act, obs, priv, &reward, &done, metrics, contact);                                     \
       write_frame_##SUF(B, N, e, d, contact); write_dbg_##SUF(B, e, d);                                                  \
       if (g_diag_resid) g_diag_resid[e] = (double)d->solver_resid_max;                                                   \
+      if (g_diag_flags) g_diag_flags[e] = d->diag_flags;                                                                 \
       int idone = done != 0;                                                                                             \
       if (cfg->autoreset) {                                                                                              \
         in.ep_steps += 1;                                                                                                \

@@ -83,6 +83,7 @@ typedef struct F(OData) {
   R qacc[ONV], efc_force[ONEFC], qfrc_constraint[ONV];
   int solver_niter;
   int solver_niter_max;          /* max over the substeps of env_step */
+  int diag_flags;                /* OR over the substeps of env_step: 1 = stale and fresh rbound pick different pair sets, 2 = a sphere centre inside a box, 4 = the cut was active */
   R solver_resid, solver_resid_max;   /* scaled gradient norm at the solver's exit (diagnostic: how far from the minimiser the cut solve is) */
   R cacc_base[6];
   R sensordata[49];
@@ -442,6 +443,27 @@ static void F(sphere_box)(const R* spos, R radius, const R* bpos, const R* bmat,
   for (int i = 0; i < 3; i++) pos_out[i] = pw[i] + bpos[i];
 }
 
+/* broad phase of the max_geom_pairs cut: dist = |pos2 - pos1| - (rbound1 + rbound2), top_k(-dist, maxp), ties -> lower index first (lax.top_k).
+   fresh = 0: the STALE compiled rbound of the placeholder boxes (what MJX sees after go2/randomize.py:97-108 replaced geom_size but not geom_rbound:
+   the reading the product and this oracle use); fresh = 1: every box's own bounding radius |half-size| (diagnostic switch only) */
+static int F(broad_phase)(const PgttModel* m, const F(OData)* d, const float* boxes, int nbox, int maxp, int fresh, int* sel) {
+  int npair = 4*nbox, nsel = 0;
+  R key[4*PGTT_MAX_BOX]; unsigned char used[4*PGTT_MAX_BOX];
+  for (int l = 0; l < 4; l++) for (int b = 0; b < nbox; b++) {
+    const float* bx = boxes + 10*b;
+    R dv[3] = {(R)bx[0] - d->foot_xpos[l][0], (R)bx[1] - d->foot_xpos[l][1], (R)bx[2] - d->foot_xpos[l][2]};
+    R hs[3] = {(R)bx[7], (R)bx[8], (R)bx[9]};
+    key[l*nbox + b] = F(norm3)(dv) - ((R)m->foot_radius[l] + (fresh ? F(norm3)(hs) : (R)m->box_rbound));
+    used[l*nbox + b] = 0;
+  }
+  for (int s = 0; s < maxp; s++) {
+    int bi = -1;
+    for (int i = 0; i < npair; i++) if (!used[i] && (bi < 0 || key[i] < key[bi])) bi = i;
+    used[bi] = 1; sel[nsel++] = bi;
+  }
+  return nsel;
+}
+
 /* boxes: nbox x 10 [pos, quat, half-size]; box_friction: nbox sliding frictions or NULL */
 static void F(collision)(const PgttModel* m, const F(OParams)* p, const float* boxes, const float* box_friction,
                          int nbox, F(OData)* d) {
@@ -479,19 +501,15 @@ static void F(collision)(const PgttModel* m, const F(OParams)* p, const float* b
   int maxp = m->max_geom_pairs, maxc = m->max_contact_points;
   int sel[4*PGTT_MAX_BOX]; int nsel = 0;
   if (maxp > -1 && npair > maxp) {
-    /* broad phase: dist = |pos2 - pos1| - (rbound1 + rbound2) with the STALE compiled rbounds; top_k(-dist, maxp),
-       ties -> lower index first (lax.top_k) */
-    R key[4*PGTT_MAX_BOX]; unsigned char used[4*PGTT_MAX_BOX];
-    for (int l = 0; l < 4; l++) for (int b = 0; b < nbox; b++) {
-      const float* bx = boxes + 10*b;
-      R dv[3] = {(R)bx[0] - d->foot_xpos[l][0], (R)bx[1] - d->foot_xpos[l][1], (R)bx[2] - d->foot_xpos[l][2]};
-      key[l*nbox + b] = F(norm3)(dv) - ((R)m->foot_radius[l] + (R)m->box_rbound);
-      used[l*nbox + b] = 0;
-    }
-    for (int s = 0; s < maxp; s++) {
-      int bi = -1;
-      for (int i = 0; i < npair; i++) if (!used[i] && (bi < 0 || key[i] < key[bi])) bi = i;
-      used[bi] = 1; sel[nsel++] = bi;
+    extern int g_oracle_fresh_rbound;
+    nsel = F(broad_phase)(m, d, boxes, nbox, maxp, g_oracle_fresh_rbound, sel);
+    {  /* diagnostic (tools/gpu_model_switch_relevance.py): would the other reading of rbound pick another set of pairs? */
+      int alt[4*PGTT_MAX_BOX]; unsigned char in[4*PGTT_MAX_BOX];
+      int na = F(broad_phase)(m, d, boxes, nbox, maxp, !g_oracle_fresh_rbound, alt);
+      for (int i = 0; i < npair; i++) in[i] = 0;
+      for (int i = 0; i < nsel; i++) in[sel[i]] = 1;
+      for (int i = 0; i < na; i++) if (!in[alt[i]]) d->diag_flags |= 1;
+      d->diag_flags |= 4;
     }
   } else {
     for (int i = 0; i < npair; i++) sel[nsel++] = i;
@@ -530,6 +548,7 @@ static void F(collision)(const PgttModel* m, const F(OParams)* p, const float* b
     F(mix_params)(zero3, m->foot_solref, m->foot_solimp, m->foot_margin, m->foot_gap, m->foot_solmix,
                   mx, m->box_solref, m->box_solimp, m->box_margin, m->box_gap, m->box_solmix, c);
     c->geom1 = l; c->geom2 = b; c->foot = l; c->box = b;
+    if (c->dist < -(R)m->foot_radius[l]) d->diag_flags |= 2;      /* an ACTIVE contact with the sphere centre inside the box: where the recalled frame flip would bite */
   }
 }
 
@@ -914,7 +933,7 @@ static void F(euler)(const PgttModel* m, F(OData)* d) {
 /* mjx_env.step(model, data, action, n_substeps): scan of { ctrl <- action ; mjx.step } */
 static void F(env_step)(const PgttModel* m, const F(OParams)* p, const float* boxes, const float* box_friction, int nbox,
                         F(OData)* d, const R* ctrl, int nsub) {
-  d->solver_niter_max = 0; d->solver_resid_max = 0;
+  d->solver_niter_max = 0; d->solver_resid_max = 0; d->diag_flags = 0;
   for (int s = 0; s < nsub; s++) {
     for (int a = 0; a < 12; a++) d->ctrl[a] = ctrl[a];
     F(forward)(m, p, boxes, box_friction, nbox, d);

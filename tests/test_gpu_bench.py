@@ -47,6 +47,10 @@ def test_driver_command_line_contract():
         assert r["traffic"] is None and r["valu_busy"] is None and r["mfma_ops"] is None
     else:
         assert 3e6 < r["traffic"] < 2e7 and 0.3 < r["valu_busy"] < 1.0
+    # round 6: the fraction against the UNPACKED fp32 ceiling (78.65 TFLOP/s) beside the stated one, and the static share of packed vector instructions
+    assert abs(r["frac_unpacked_ceiling"] - r["achieved"] / 78.65) < 1e-9 and abs(r["frac_unpacked_ceiling"] - 2 * r["frac"]) < 1e-3
+    isa = json.load(open(os.path.join(ROOT, "profiles", "isa_static.json")))
+    assert (r["valu_packed_share"] == isa["valu_packed_share"]) if isa["csrc_sha256"] == info["src"] else (r["valu_packed_share"] is None)
     k = d["kernels_ms"]
     assert k["launches"] >= 3 and 0.05 < k["physics_kernel"] < 0.3 and 0.005 < k["observe_kernel"] < 0.05
     assert k["physics_kernel"] + k["observe_kernel"] < d["ms_per_step"] * 1.05          # the kernels fit inside the step they are part of

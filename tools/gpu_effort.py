@@ -50,6 +50,11 @@ print("  Newton trips of an env in one substep: " + "  ".join(f"{k}: {100 * hist
 print(f"  an env on its own: trips {(rec > 0).sum(2).mean():.2f}, rounds {np.maximum(rec - 1, 0).sum(2).mean():.1f}; solver ticks {np.mean(tot['alone']):.0f}")
 for k in ("fixed", "sorted", "oracle"):
     print(f"  {k:7s}: solver ticks of the mean wave {np.mean(tot[k + '_mean']):9.0f}   of the slowest wave {np.mean(tot[k]):9.0f}")
+# round 6: the CEILING of any de-synchronised bracketing - a wave whose envs each follow their own (trip, round) cursor can at best
+# last as long as its slowest env's own path (exec-masked paths of different stages add up, they do not overlap): mean / slowest wave of max_env own ticks
+own_w = np.stack([own(rec[t]).reshape(n // G, G).max(1) for t in range(1, len(rec))])
+print(f"  de-synchronised ceiling (max over a wave's envs of the env's OWN solver ticks): mean wave {own_w.mean():9.0f}   slowest wave {own_w.max(1).mean():9.0f}"
+      f"   -> the launch lasts as long as its slowest wave: {np.mean(tot['fixed']):.0f} today, {own_w.max(1).mean():.0f} at the ceiling ({100 * (1 - own_w.max(1).mean() / np.mean(tot['fixed'])):.1f} % of the solver ticks)")
 a, b = own(rec[1:].reshape(-1, 20)).reshape(len(rec) - 1, n), own(rec[:-1].reshape(-1, 20)).reshape(len(rec) - 1, n)
 print(f"  correlation of an env's solver work with its previous step's: {np.corrcoef(a.ravel(), b.ravel())[0, 1]:.3f}")
 hess = np.stack(hess)[51:]
