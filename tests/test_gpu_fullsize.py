@@ -134,6 +134,94 @@ def test_episode_and_autoreset_semantics(observe):
     env.close()
 
 
+@pytest.mark.parametrize("observe", ["fused", "split"])
+def test_wrapper_contract_row_by_row_on_a_hand_built_trajectory(observe, golden_dir):
+    """The reference states its wrapper contract in two places only: `episode_length` + `wrap_for_brax_training` (training/train.py:255,262) and the
+    evaluator keys training/evaluate.py:203-215 reads (`eval/episode_reward`, `eval/episode_reward/tracking_*`, `eval/avg_episode_length` = means over the
+    envs of the Episode wrapper's running sums at the end of each env's first episode).  SURVEY 8b (ii) / (iii) [UPSTREAM-RECALL] spell the semantics
+    out.  Here a trajectory with KNOWN episode boundaries goes through pgtt_step with episode_length = 7: envs 0..15 are turned on their backs before
+    control step 2 (termination there), envs 16..31 before control step 6 (termination AND the length limit in the same step), the rest run into the
+    limit at step 6.  A twin handle without the wrappers is put on the wrapped env's state before every step, so that it shows what the bare
+    `Joystick.step` returns from the same state.  Asserted row by row: `done`, the truncation flag (1 - termination at the limit), the running episode
+    sums against a host restatement of `x = (x + v) * (1 - prev_done)`, the restore of the first reset's physics rows and observations, EVERY task
+    `info` row surviving the restore, and evaluate.py's aggregation of the first episodes."""
+    n, L = 64, 7
+    cfg = configs.with_overrides(configs.training_config(), episode_length=L)
+    A, _, var = make(n=n, cfg=cfg, variant=np.zeros(n, dtype=np.int32), observe_form=observe)
+    B, _, _ = make(n=n, cfg=cfg, variant=np.zeros(n, dtype=np.int32), observe_form=observe, autoreset=False)
+    # the metric rows carry the reference's names (reference-held: the key set of Joystick.reset's metrics dict, tests/golden/task_reset.npz)
+    ref_keys = [str(k) for k in np.load(os.path.join(golden_dir, "task_reset.npz"), allow_pickle=False)["r0_metrics_keys"]]
+    assert sorted(["reward/" + k for k in abi.REWARD_KEYS] + ["swing_peak"]) == ref_keys and abi.NMETRIC == len(ref_keys)
+    i_lin, i_ang = abi.REWARD_KEYS.index("tracking_lin_vel"), abi.REWARD_KEYS.index("tracking_ang_vel")     # what evaluate.py:213-214 reads
+    A.reset(seed=5); B.reset(seed=5)
+    torch.cuda.synchronize()
+    first_state, first_obs = A.buffers["first_state"].clone(), A.buffers["first_obs"].clone()
+    E = np.zeros((abi.NMETRIC + 2, n), np.float32)                         # host restatement of the Episode wrapper's sums
+    prev_done = np.zeros(n, bool)
+    first = np.ones(n, bool); ev_ret = np.zeros(n, np.float32); ev_len = np.zeros(n, np.float32); ev_terms = np.zeros((abi.NMETRIC, n), np.float32)
+    ep_at_first_done = np.zeros((abi.NMETRIC + 2, n), np.float32)
+    ep_steps = np.zeros(n, np.int64)
+    expect_done = {2: set(range(0, 16)), 6: set(range(16, n)), 9: set(range(0, 16)), 13: set(range(16, n))}
+    for k in range(15):
+        if k in (2, 6):                                                        # hand-built boundary: these robots are on their backs now
+            idx = torch.arange(0, 16) if k == 2 else torch.arange(16, 32)
+            A.buffers["state"][abi.S_QPOS + 3:abi.S_QPOS + 7, idx] = torch.tensor([0.0, 1.0, 0.0, 0.0], device="cuda:0")[:, None]
+        for key in ("state", "istate", "scan_z"):                              # the twin steps from the SAME state, without Episode / AutoReset
+            B.buffers[key].copy_(A.buffers[key])
+        a = actions(k, n)
+        obs, reward, done, info = A.step(a)
+        obsB, rewardB, doneB, infoB = B.step(a)
+        torch.cuda.synchronize()
+        gA = {kk: v.cpu().numpy() for kk, v in A.buffers.items()}; gB = {kk: v.cpu().numpy() for kk, v in B.buffers.items()}
+        term = gB["done"] != 0                                                  # the bare env's done = termination
+        ep_steps = np.where(prev_done, 0, ep_steps) + 1
+        d = term | (ep_steps >= L)
+        assert np.array_equal(gA["done"] != 0, d), k                            # EpisodeWrapper: done |= steps >= episode_length
+        assert set(np.nonzero(d)[0]) == expect_done.get(k, set()), (k, np.nonzero(d)[0])
+        assert np.array_equal(gA["istate"][abi.I_EP_STEPS], ep_steps), k
+        trunc = (ep_steps >= L) & ~term                                         # truncation = 1 - termination at the limit
+        if k == 2:
+            assert term[:16].all() and not trunc.any()
+        if k == 6:
+            assert term[16:32].all() and not trunc[16:32].any() and trunc[32:].all() and (gA["frame"][abi.F_UPVECTOR + 2, 16:32] < 0).all()
+        # reward / metrics of the step are the bare env's, bit for bit
+        assert np.array_equal(gA["reward"], gB["reward"]) and np.array_equal(gA["metrics"], gB["metrics"]), k
+        # running episode sums: x = (x + v) * (1 - prev_done), rows = 22 metrics, sum_reward, length
+        keep = np.where(prev_done, np.float32(0), np.float32(1))
+        E[:abi.NMETRIC] = (E[:abi.NMETRIC] + gA["metrics"]) * keep
+        E[abi.NMETRIC] = (E[abi.NMETRIC] + gA["reward"]) * keep
+        E[abi.NMETRIC + 1] = (E[abi.NMETRIC + 1] + np.float32(1)) * keep
+        for r in range(abi.NMETRIC + 2):
+            assert np.array_equal(gA["ep_metrics"][r], E[r]), (k, r)
+        # AutoReset: physics rows and observations of a done env are the FIRST reset's, the others the bare env's
+        for r in range(abi.S_CMD):
+            assert np.array_equal(gA["state"][r], np.where(d, first_state[r].cpu().numpy(), gB["state"][r])), (k, r)
+        fo = first_obs.cpu().numpy()
+        assert np.array_equal(gA["obs_state"], np.where(d[:, None], fo[:, :abi.OBS], gB["obs_state"])), k
+        assert np.array_equal(gA["obs_priv"], np.where(d[:, None], fo[:, abi.OBS:], gB["obs_priv"])), k
+        # ... while EVERY task info row survives the restore: command, phase, gait frequency, last actions, air time, swing peak, H_max / H_min,
+        # motor targets, both histories, last contact - and the task's own counters
+        for r in range(abi.S_CMD, abi.NSTATE):
+            assert np.array_equal(gA["state"][r], gB["state"][r]), (k, r)
+        for r in (abi.I_STEP, abi.I_STEPS_UNTIL_CMD, abi.I_RNG_CTR):
+            assert np.array_equal(gA["istate"][r], gB["istate"][r]), (k, r)
+        # the evaluator's view (training/evaluate.py:203-215 through brax's Evaluator): sums over each env's FIRST episode
+        w = first.astype(np.float32)
+        ev_ret += gA["reward"] * w; ev_len += w; ev_terms += gA["metrics"] * w
+        newly = first & d
+        ep_at_first_done[:, newly] = gA["ep_metrics"][:, newly]
+        first &= ~d
+        prev_done = d
+    assert not first.any()
+    # at the step an episode ends the wrapper's sums ARE the evaluator's: eval/episode_reward, eval/episode_reward/<term>, eval/avg_episode_length
+    assert np.array_equal(ep_at_first_done[abi.NMETRIC], ev_ret) and np.array_equal(ep_at_first_done[abi.NMETRIC + 1], ev_len)
+    for r in (i_lin, i_ang):
+        assert np.array_equal(ep_at_first_done[r], ev_terms[r])
+    assert ev_len.mean() == (16 * 3 + 48 * 7) / 64.0 and (ev_len[:16] == 3).all() and (ev_len[16:] == 7).all()
+    assert (A.buffers["istate"][abi.I_STEP] == 15).all()                       # the task's step counter never restarts
+    A.close(); B.close()
+
+
 def _tops(boxes, pts):
     """analytic terrain height under (x, y) for yaw-only boxes resting on z = 0"""
     top = np.zeros(len(pts))
