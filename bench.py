@@ -62,7 +62,7 @@ REDUCE_EVERY = 20                       # log interval of the metric all-reduce 
 COLD_RATIO = 1.5
 # untimed steps after the reset before the clock starts.  SURVEY 8d asks for 100 (the robots' landing); the DEVICE asks for more: in a fresh
 # process the first ~100 control steps (~20 ms of GPU time) run up to 13 % slower than the same steps of a second roll-out in the same
-# process (profiles/r03_step_profile.txt: physics_kernel 190 / 178 / 173 / 169 us over the first four blocks of 25 steps, 168 from the
+# process (profiles/archive/r03_step_profile.txt: physics_kernel 190 / 178 / 173 / 169 us over the first four blocks of 25 steps, 168 from the
 # first block when the roll-out is repeated) - clocks ramping, not the simulation.  BASELINE.md quotes the metric on the steady state, and
 # the driver's command times 20 steps: 1500 steps (0.3 s at 4096 envs) put that window where the 300-step default already is.
 PRIME_STEPS = 1500

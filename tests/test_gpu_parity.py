@@ -105,7 +105,7 @@ def per_env_errors(g, hb):
 W_FLOOR = {4: 0.72, 1: 0.81}                 # measured - 5 points
 VIOL_CAP = {4: dict(qpos=0.003, qvel=0.004, warm=0.008, info=0.003, hist=0.006, scan=0.002, obs=0.004, priv=0.005, frame=0.005, reward=0.003, metrics=0.006),
             1: dict(qpos=0.0015, qvel=0.0015, warm=0.004, info=0.0015, hist=0.004, scan=0.002, obs=0.003, priv=0.004, frame=0.004, reward=0.0015, metrics=0.004)}
-# Round 3 (profiles/r03_parity_p90.txt): percentiles of the GPU-vs-oracle error next to the oracle's own fp32-vs-fp64 error.
+# Round 3 (profiles/archive/r03_parity_p90.txt): percentiles of the GPU-vs-oracle error next to the oracle's own fp32-vs-fp64 error.
 #   on W:        GPU p90 / oracle p90 = 1.26-1.47 (qpos 3 ulp vs 2 ulp of a unit coordinate), p99 1.2-1.45; observation / sensor-frame rows (relative):
 #                p99.9 = 1.8e-3 .. 4.4e-3  ->  tolerances below = 2 x that (they were 2e-2);
 #   all steps:   p90 ratio 1.8-2.0 - with the correctly rounded division / sqrt build (make PRECISE_DIV=1) just the same (1.8-2.2), and the ORACLE's two fp32
@@ -297,7 +297,7 @@ def run_parity(task, n, terrain, steps, dr=False, autoreset=False, noise=1.0, me
             pw_g, pw_f = np.percentile(gq[Wm], 90), np.percentile(fq[Wm], 90)
             stats[f"p90_{key}"] = (float(pw_g), float(pw_f))
             assert pw_g <= P90_W_RATIO * pw_f + P90_FLOOR[key], (key, "W", pw_g, pw_f)
-            if nsub == 4 and (~Wm).sum() >= 2000:                 # measured for the control step (profiles/r03_parity_p90.txt)
+            if nsub == 4 and (~Wm).sum() >= 2000:                 # measured for the control step (profiles/archive/r03_parity_p90.txt)
                 mo_g, mo_f = np.median(gq[~Wm]), np.median(fq[~Wm])
                 stats[f"p90_{key}"] += (float(mo_g), float(mo_f))
                 assert mo_g <= P90_ALL_RATIO * mo_f + 20 * P90_FLOOR[key], (key, "outside W", mo_g, mo_f)

@@ -71,7 +71,7 @@ def test_sphere_box_decision_is_regression_guarded_by_the_flip_build():
     honest: the SAME rollouts in the -DPGTT_SPHERE_CONVEX_FLIP build (libpgtt_flip.so, same sources, one switch) must FAIL what the
     product passes - the contact duty of policy177's normaliser (0.444 over 443 M samples of the reference's simulator: product 0.441,
     flip build 0.55-0.64), the base height on a 6 cm slab (+ 6 cm solid, + 2 cm sinking) - and the run records how often a box
-    contact is deeper than the radius at all (profiles/r03_penetration_hist.txt)."""
+    contact is deeper than the radius at all (profiles/archive/r03_penetration_hist.txt)."""
     prod, flip = _flip_stats("libpgtt.so"), _flip_stats("libpgtt_flip.so")
     print("product", {k: prod[k] for k in ("contact_duty", "slab_base_gain_m", "frac_deeper_than_radius", "max_penetration_m", "std_ratio")})
     print("flip   ", {k: flip[k] for k in ("contact_duty", "slab_base_gain_m", "frac_deeper_than_radius", "max_penetration_m", "std_ratio")})

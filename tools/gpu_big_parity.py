@@ -1,5 +1,5 @@
 """Large-sample run of the parity harness (tests/test_gpu_parity.run_parity): 1024 envs x 100 control steps on level4 per layout and
-512 x 80 on level13 with full DR.  Its output is kept as profiles/r02d_parity_big.txt / r02e_parity_big_oct.txt.   usage: python tools/gpu_big_parity.py [layout ...]"""
+512 x 80 on level13 with full DR.  Its output is kept as profiles/archive/r02d_parity_big.txt / r02e_parity_big_oct.txt.   usage: python tools/gpu_big_parity.py [layout ...]"""
 import os, sys, numpy as np
 sys.path.insert(0, os.getcwd())
 import tests.test_gpu_parity as T

@@ -70,7 +70,7 @@ def summarise(name, eg, ef, ni, fm, sm, rs):
 
 def ratios(lay="hex"):
     """p50 / p90 / p99 of the GPU-vs-oracle error next to the oracle's own fp32-vs-fp64 error, all env-steps and W, for whichever build PGTT_LIB names:
-    the column of profiles/r03_parity_p90.txt (product, and `make PRECISE_DIV=1`)"""
+    the column of profiles/archive/r03_parity_p90.txt (product, and `make PRECISE_DIV=1`)"""
     from phase_guided_terrain_traversal_amd import native
     A = os.path.join(ROOT, "phase_guided_terrain_traversal_amd", "assets", "terrains")
     P.EXEC["layout"] = lay

@@ -1,5 +1,5 @@
 # where do the cycles of physics_kernel that are not VALU issue go?  memory instructions in flight, scalar / branch counts, instruction
-# cache (counter passes only, five runs of the short bench; run through gpurun:  bash tools/pmc_waits.sh) -> profiles/r02e_physics_waits.txt
+# cache (counter passes only, five runs of the short bench; run through gpurun:  bash tools/pmc_waits.sh) -> profiles/archive/r02e_physics_waits.txt
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/waits; mkdir -p $O
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline ${BENCH_ARGS}"
 rocprofv3 --pmc SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_INSTS_LDS SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS -d $O/a -o p --output-format csv -- $B > /dev/null 2>&1
