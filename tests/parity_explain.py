@@ -252,9 +252,9 @@ def scan_ensemble(cs, ed: EnvData, qpos_orc: np.ndarray, qpos_dev: np.ndarray, s
 # ---------------------------------------------------------------------------------------------------------------- providers of the device's substeps
 class DeviceSubsteps:
     """the HIP kernels, one mjx.step per launch: a second handle with ctrl_dt = sim_dt (n_substeps = 1) on the SAME lane layout and the SAME batch,
-    physics only.  The whole batch is replayed, not the envs in question alone: the oct and hex layouts split a wave's contact work by the number
-    of box slots in use ANYWHERE in the wave, so an env's roundings depend on the company it keeps in its wave (bit-identity holds for a fixed
-    grouping of envs into waves - shards that start at a multiple of 16 envs - which is what DESIGN.md 4 / 7 claim)."""
+    physics only.  The whole batch is replayed, not the envs in question alone: the oct layout splits a wave's contact work by the number of box
+    slots in use ANYWHERE in the wave, so an env's roundings depend on the company it keeps in its wave there (profiles/r06_wave_company.txt; quad and
+    hex do not)."""
 
     def __init__(self, task, cfg, model, terrain, layout, n, opt: Dict[str, np.ndarray]):
         import torch
