@@ -1,22 +1,28 @@
 """Post-mortem of the env-steps of W on which the device (HIP kernels) and the fp32 oracle end up further apart than the bar - TEST INFRASTRUCTURE
 (imports the oracle; used by tests/test_gpu_parity.py, tests/test_gpu_fullsize.py, tests/test_parity_explain.py and tools/gpu_parity_stats.py).
 
-Until round 5 the parity suite held such env-steps to RATES (twice the measured ones).  Here every one of them is replayed substep by substep
-and has to show one of the two causes DESIGN.md 3 names - or the test fails:
+Until round 5 the parity suite held such env-steps to RATES (twice the measured ones).  Here every one of them is replayed substep by substep on
+both sides, every substep is judged on its own input against a* = the minimiser of that substep's convex problem (fp64 oracle, caps lifted to
+100 iterations x 60 line-search rounds), and the env-step has to show a cause - or the test fails:
 
-  * `cap`   the reference truncates Newton at `iterations` = 5 (go2/xmls/go2_mjx_feetonly.xml:17).  From the DEVICE's own input to a substep,
-            a* = the minimiser of that substep's convex problem (fp64 oracle, caps lifted to 100 iterations x 60 line-search rounds).  The cause is
-            `cap` when one side's acceleration is off a* (dt |a - a*| > 5e-4 or |a - a*| / (1 + |a*|) > 2e-3: a tenth of the bars) AND that side
-            stopped because it ran out of iterations (niter == iterations); also when the fp64 oracle itself, at the reference's caps, is cut on
-            the device's input (the env-step sits on the edge of W).  A side that is off the minimiser WITHOUT having hit the cap is `unexplained`.
-  * `sign`  the ACTIVE contact sets of the device and of the fp64 oracle differ on the same input, and every pair in the difference has
-            |dist| < SIGN_TOL x max(1, |foot position|): a distance within rounding of 0 changed sides.  A differing pair that is not that close is
-            `unexplained`.
-  * `downstream`  the physics state at the end of the control step is inside the bar (qpos, qvel, warm start, flags, sets) and only derived rows
-            (scan, observations, sensor frame, rewards ...) miss theirs: handled by `explain_downstream`.
+  * `cap`      the reference truncates Newton at `iterations` = 5 (go2/xmls/go2_mjx_feetonly.xml:17).  A side's acceleration is off a*
+               (dt |a - a*| > 5e-4 or |a - a*| / (1 + |a*|) > 2e-3: a tenth of the bars) AND that side stopped because it ran out of iterations
+               (niter == iterations); also when the fp64 oracle itself, at the reference's caps, is cut on that input (the edge of W).
+  * `floor`    a side is off a* and stopped by the solver's improvement test, with a cost within FLOOR_ULPS fp32 roundings of the cost's terms of the
+               minimum: the fp32 cost cannot resolve the remaining descent.
+  * `sign`     the ACTIVE contact sets of a side and of the fp64 oracle differ on the same input, and every pair in the difference has
+               |dist| < SIGN_TOL x max(1, |foot position|): a distance within rounding of 0 changed sides.
+  * `tie`      a side lands where the fp32 ORACLE lands from the same input, off the fp64 minimiser, and a sphere centre is within SIGN_TOL of the
+               SURFACE of a box: the normal of mjx's sphere-box routine is the direction of a zero-length vector there (frame_tie).
+  * `unstable` none of the above fits, but the fp32 oracle's control step misses the bar against ITSELF, on every physics row in question, when its
+               input moves by <= ENSEMBLE_ULPS fp32 roundings per component (rounding_ensemble): the reference's answer depends on rounding there.
+  * `edge`     physics identical to rounding on both sides, a scan ray differs: the fp32 oracle's own scan moves by at least half as much under the
+               same input rounding (scan_ensemble): the ray sits on a box edge or a near-vertical face.
+  * `unexplained`  anything else - a side off the minimiser without having hit the cap or the floor, a contact pair that differs at a distance that
+               is not small, a replay that does not reproduce the control step's bits.
 
-The replay runs ONE mjx.step per call on the device (a second handle with ctrl_dt = sim_dt, same lane layout; physics only) and must reproduce the
-bits of the control step it explains - otherwise the verdict is `unexplained: replay`.
+The replay runs ONE mjx.step per call on the device (a second handle with ctrl_dt = sim_dt, same lane layout, the WHOLE batch; physics only) and must
+reproduce the bits of the control step it explains; the fp32 oracle's replay likewise.
 """
 from __future__ import annotations
 
