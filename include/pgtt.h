@@ -149,7 +149,8 @@ typedef struct PgttConfig {
                                    * between batch sizes / shards only WITHIN one layout (between layouts: fp32 rounding), so a job that must
                                    * reproduce another one's bits pins the layout here.  In the OCT layout an env's roundings also depend on the
                                    * other seven envs of its wave (the plane contact joins the sub-lane split when any of them holds two box
-                                   * contacts): there the shards must start at multiples of 8 envs as well.  QUAD and HEX do not care. */
+                                   * contacts): there the shards must start at multiples of 8 envs as well.  QUAD does not care; HEX only when a foot of
+                                   * the wave holds four box contacts (multiples of 4 envs then). */
   int32_t observe_form;           /* PGTT_OBSERVE_*: scan + obs + rewards as one kernel or as observe + task kernels */
   int32_t test_hooks;             /* non-zero: pgtt_set_test_overrides is allowed on this handle (fixture replay); 0 in production */
 } PgttConfig;
