@@ -130,8 +130,15 @@ def judge_substep(ms, ms_long, ed: EnvData, inp, ctrl, sub: Dict, side: str) -> 
         return out                 # another constraint set: another problem, its minimiser is not a*
     o64 = off_minimiser(D64["qacc"], astar, dt)
     if is_off(*o64):               # the fp64 oracle at the reference's caps is itself cut on this input: the edge of W
-        out.append(dict(side="fp64 oracle", cause="cap" if D64["niter"] >= iters else "unexplained", dv=o64[0], rel=o64[1],
-                        detail=f"fp64 oracle cut at the cap on the {side}'s input (dv {o64[0]:.3g}, rel {o64[1]:.3g}, niter {int(D64['niter'])})"))
+        cause64, which = ("cap", "iteration") if D64["niter"] >= iters else ("unexplained", "")
+        if cause64 == "unexplained":
+            # stopped before the iteration cap and still off the minimiser, in fp64: the OTHER cap of go2_mjx_feetonly.xml:17 - a line search that ran out
+            # of its 5 rounds without finding a lower cost returns alpha = 0, the improvement test then ends the solve.  Shown by lifting that cap alone.
+            Dl = oracle.forward(model_copy(ms, ls_iterations=LONG_LS), qpos, qvel, ctrl, warm, fp64=True, **kw)
+            if Dl["niter"] >= iters or not is_off(*off_minimiser(Dl["qacc"], astar, dt)):
+                cause64, which = "cap", "line-search round"
+        out.append(dict(side="fp64 oracle", cause=cause64, dv=o64[0], rel=o64[1],
+                        detail=f"fp64 oracle cut at the {which} cap on the {side}'s input (dv {o64[0]:.3g}, rel {o64[1]:.3g}, niter {int(D64['niter'])})"))
     off = off_minimiser(sub["qacc"], astar, dt)
     if is_off(*off):
         ni = int(sub["niter"])
@@ -150,6 +157,56 @@ def judge_substep(ms, ms_long, ed: EnvData, inp, ctrl, sub: Dict, side: str) -> 
                 if tie:
                     cause, detail = "tie", f"{side} = the fp32 oracle on the same input (niter {int(D32['niter'])}); fp32 and fp64 build different contact frames there: {tie}"
         out.append(dict(side=side, cause=cause, dv=off[0], rel=off[1], gap_ulps=gap, niter=ni, detail=detail))
+    return out
+
+
+def substep_ensemble(ms, ed: EnvData, inp, ctrl, seed: int = 0) -> tuple:
+    """ONE mjx.step of the fp32 oracle from ENSEMBLE copies of the input moved by <= ENSEMBLE_ULPS roundings per component, against the unperturbed
+    one -> (dt max|a_k - a_0|, max relative): how far the reference algorithm's own answer moves under input rounding on this substep"""
+    rng = np.random.default_rng(seed)
+    kw = dict(boxes=ed.boxes, box_friction=ed.box_friction, params=ed.params)
+    x = np.concatenate([np.asarray(v, np.float32) for v in inp])
+    base = oracle.forward(ms, x[:19], x[19:37], ctrl, x[37:55], fp64=False, **kw)["qacc"]
+    dv = rel = 0.0
+    for _ in range(ENSEMBLE):
+        k = rng.integers(-ENSEMBLE_ULPS, ENSEMBLE_ULPS + 1, size=55)
+        y = (x.astype(np.float64) + k * np.spacing(np.abs(x)).astype(np.float64)).astype(np.float32)
+        o = off_minimiser(oracle.forward(ms, y[:19], y[19:37], ctrl, y[37:55], fp64=False, **kw)["qacc"], base, float(ms.timestep))
+        dv, rel = max(dv, o[0]), max(rel, o[1])
+    return dv, rel
+
+
+def audit_substep(ms, ms_long, ed: EnvData, inp, ctrl, sub: Dict, seed: int = 0) -> Dict:
+    """W-free statement about ONE mjx.step of the device: its acceleration is the minimiser of the substep's convex problem (to a tenth of the bars, with
+    the fp64 oracle's contact set) -> "minimiser"; or it shows why not -> "cap" / "floor" / "sign" / "tie" / "edge of W" (the fp64 oracle at the
+    reference's caps is cut on this input) / "unstable" (the fp32 oracle's own answer moves at least half as far under <= 2 roundings of the input);
+    anything else is "unexplained" """
+    an = judge_substep(ms, ms_long, ed, inp, ctrl, sub, "device")
+    if not an:
+        return dict(cause="minimiser", detail="")
+    bad = [a for a in an if a["cause"] == "unexplained"]
+    if bad:
+        dv, rel = substep_ensemble(ms, ed, inp, ctrl, seed)
+        b = bad[0]
+        if np.isfinite(b["dv"]) and dv >= 0.5 * b["dv"] and rel >= 0.5 * b["rel"]:
+            return dict(cause="unstable", detail=f"{b['detail']}; the fp32 oracle's own answer moves by dv {dv:.3g}, rel {rel:.3g} under <= {ENSEMBLE_ULPS} roundings of the input")
+        return dict(cause="unexplained", detail=f"{b['detail']}; fp32 oracle under input rounding: dv {dv:.3g}, rel {rel:.3g}")
+    top = max(an, key=lambda a: (a["dv"], a["rel"]))
+    return dict(cause="edge of W" if top["side"] == "fp64 oracle" else top["cause"], detail=top["detail"])
+
+
+def audit_control_step(ms, hb, terrain, S0: np.ndarray, ctrl_rows: np.ndarray, dev: List[List[Dict]], cols, seed: int = 0) -> List[Dict]:
+    """audit_substep over every substep of the envs `cols` (dev = the device's substeps of exactly those envs) -> records {env, substep, cause, detail}"""
+    ms_long = model_copy(ms, iterations=LONG_ITER, ls_iterations=LONG_LS)
+    out = []
+    for i, e in enumerate(cols):
+        e = int(e)
+        ed = env_data(hb, terrain, e)
+        inp = (S0[:19, e].astype(np.float64), S0[19:37, e].astype(np.float64), S0[37:55, e].astype(np.float64))
+        for s_, sub in enumerate(dev[i]):
+            v = audit_substep(ms, ms_long, ed, inp, ctrl_rows[:, e].astype(np.float64), sub, seed=seed + 4 * e + s_)
+            out.append(dict(env=e, substep=s_, niter=int(sub["niter"]), **v))
+            inp = (sub["qpos"].astype(np.float64), sub["qvel"].astype(np.float64), sub["qacc"].astype(np.float64))
     return out
 
 

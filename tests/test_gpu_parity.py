@@ -348,6 +348,40 @@ def test_one_substep_launches_reproduce_the_control_step(layout):
         env.close()
 
 
+def test_every_device_substep_is_the_minimiser_or_says_why(layout):
+    """A statement that needs no W and no oracle trajectory: EVERY mjx.step the kernels take along a rollout - no selection by convergence, none by
+    violation - returns the minimiser of that substep's convex problem (fp64 oracle from the device's own input, caps lifted) to a tenth of the bars with
+    the fp64 oracle's ACTIVE contact set, or shows why not: it stopped at the iteration cap (`cap`; the fp64 oracle at the reference's caps is cut there
+    too: `edge of W`), on the fp32 resolution of its cost (`floor`), a contact distance or a sphere centre sits within 1e-6 of a surface (`sign` / `tie`),
+    or the fp32 oracle's own answer moves as far under two roundings of the input (`unstable`).  Nothing may be left unexplained.  level4 and the flat
+    task with DR; tests/test_parity_explain.py makes the same statement about a second fp32 build of the oracle, on the CPU."""
+    terrain = np.load(os.path.join(ASSETS, "terrains", "level4.npy"))
+    for task, ter, dr, n, steps in (("stairs", terrain, False, 256, 10), ("flat_terrain", None, True, 128, 8)):
+        env, hb, cs, ms = make_pair(task, n, ter, dr=dr)
+        env.reset(3)
+        rng = np.random.default_rng(4)
+        for _ in range(12):                                                      # the landing
+            env.step(torch.from_numpy(np.tanh(rng.normal(size=(n, 12)) * 0.6).astype(np.float32)).cuda())
+        dev = X.DeviceSubsteps(task, env.config, env.model, ter, layout, n, {kk: hb[kk] for kk in ("params", "variant", "box_friction") if kk in hb.arrays})
+        tally, cols = {}, np.arange(n)
+        for k in range(steps):
+            torch.cuda.synchronize()
+            S0 = env.buffers["state"].cpu().numpy()
+            act = np.tanh(rng.normal(size=(n, 12)) * 0.6).astype(np.float32)
+            env.step(torch.from_numpy(act).cuda())
+            torch.cuda.synchronize()
+            fin = env.buffers["state"].cpu().numpy()
+            subs = dev(cols, S0, act, None, 4)
+            rep = np.stack([np.concatenate([s_[-1]["qpos"], s_[-1]["qvel"], s_[-1]["qacc"]]) for s_ in subs], 1)
+            assert np.array_equal(rep, fin[:55]), k
+            for r in X.audit_control_step(ms, hb, ter, S0, fin[abi.S_MOTOR_TARGETS:abi.S_MOTOR_TARGETS + 12], subs, cols, seed=1000 * k):
+                tally[r["cause"]] = tally.get(r["cause"], 0) + 1
+                assert r["cause"] != "unexplained", (task, k, r)
+        print(f"\n[{task} dr={dr} {layout}] every substep of {n * steps} env-steps:", tally)
+        assert tally["minimiser"] > 0.7 * 4 * n * steps and tally.get("cap", 0) + tally.get("edge of W", 0) > 0
+        dev.close(); env.close()
+
+
 def test_flat_parity(layout):
     st = run_parity("flat_terrain", 256, None, steps=40)
     assert st["active_contacts"] > 1000

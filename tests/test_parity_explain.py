@@ -79,3 +79,35 @@ def test_fp32_pair_violations_on_W_are_all_explained(wl):
         print("   ", r["step"], r["env"], r["keys"], r["cause"], "substep", r["substep"], "-", r["detail"])
     assert well_total > 0.7 * n * steps
     assert not ledger.unexplained(), ledger.unexplained()[:5]
+
+
+def test_every_substep_of_a_second_fp32_build_is_the_minimiser_or_says_why():
+    """the W-free statement of tests/test_gpu_parity.py::test_every_device_substep_is_the_minimiser_or_says_why, on the CPU: EVERY mjx.step of the
+    oracle's -O3 -march=native fp32 build along a level4 rollout (no selection by W, none by violation) returns the minimiser of its convex problem to a
+    tenth of the bars, or stopped at the iteration cap / on the fp32 floor of the cost / sits on a geometric tie - nothing is left unexplained"""
+    try:
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "fast"], check=True)
+    except Exception:
+        pytest.skip("no compiler for the -march=native build")
+    fastpath = os.path.join(ROOT, "oracle", "_fast", "liboracle_fast.so")
+    n, steps = 48, 10
+    terrain = np.load(os.path.join(ASSETS, "terrains", "level4.npy"))
+    cfg = configs.training_config()
+    cs, ms = abi.config_struct(cfg), abi.model_struct(mjcf.load_model("stairs"))
+    a = oracle.HostBuffers(n, with_variant=True)
+    a["variant"][:] = np.random.default_rng(2).integers(0, terrain.shape[0], n).astype(np.int32)
+    oracle.reset(cs, ms, terrain, a, seed=3, nthreads=8)
+    rng = np.random.default_rng(1)
+    subs = X.OracleSubsteps(fastpath, ms, lambda e: X.env_data(a, terrain, e))
+    tally = {}
+    for k in range(steps):
+        S0 = a["state"].copy()
+        act = np.tanh(rng.normal(size=(n, 12)) * 0.6).astype(np.float32)
+        step_with(oracle.lib(), cs, ms, terrain, a, act)
+        ctrl = a["state"][abi.S_MOTOR_TARGETS:abi.S_MOTOR_TARGETS + 12]
+        cols = np.arange(n)
+        for r in X.audit_control_step(ms, a, terrain, S0, ctrl, subs(cols, S0, act, ctrl, 4), cols, seed=1000 * k):
+            tally[r["cause"]] = tally.get(r["cause"], 0) + 1
+            assert r["cause"] != "unexplained", r
+    print("\nevery substep of", n * steps, "env-steps:", tally)
+    assert tally["minimiser"] > 0.7 * 4 * n * steps and tally.get("cap", 0) > 0
