@@ -192,7 +192,21 @@ def audit_substep(ms, ms_long, ed: EnvData, inp, ctrl, sub: Dict, seed: int = 0)
             return dict(cause="unstable", detail=f"{b['detail']}; the fp32 oracle's own answer moves by dv {dv:.3g}, rel {rel:.3g} under <= {ENSEMBLE_ULPS} roundings of the input")
         return dict(cause="unexplained", detail=f"{b['detail']}; fp32 oracle under input rounding: dv {dv:.3g}, rel {rel:.3g}")
     top = max(an, key=lambda a: (a["dv"], a["rel"]))
-    return dict(cause="edge of W" if top["side"] == "fp64 oracle" else top["cause"], detail=top["detail"])
+    out = dict(cause="edge of W" if top["side"] == "fp64 oracle" else top["cause"], detail=top["detail"])
+    if out["cause"] in ("cap", "edge of W"):
+        # a cut solve has no right answer to be compared with - but it has a QUALITY: how far above the minimum did the device stop, and how far does the
+        # fp32 oracle stop from the same input?  (the caller compares the two populations: a slower-converging device would show here and nowhere else)
+        qpos, qvel, warm = inp
+        kw = dict(boxes=ed.boxes, box_friction=ed.box_friction, params=ed.params)
+        D64 = oracle.forward(ms, qpos, qvel, ctrl, warm, fp64=True, **kw)
+        if active_set(D64["con_foot"], D64["con_box"], D64["con_dist"]) == active_set(np.asarray(sub["con"]).reshape(8, 2)[:, 0], np.asarray(sub["con"]).reshape(8, 2)[:, 1], sub["dist"]):
+            astar = oracle.forward(ms_long, qpos, qvel, ctrl, warm, fp64=True, **kw)["qacc"]
+            D32 = oracle.forward(ms, qpos, qvel, ctrl, warm, fp64=False, **kw)
+            c0, mag = cost_terms(D64, astar)
+            out["gap_dev"] = (cost_terms(D64, sub["qacc"])[0] - c0) / (EPS32 * mag)
+            out["gap_o32"] = (cost_terms(D64, D32["qacc"])[0] - c0) / (EPS32 * mag)
+            out["niter_o32"] = int(D32["niter"])
+    return out
 
 
 def audit_control_step(ms, hb, terrain, S0: np.ndarray, ctrl_rows: np.ndarray, dev: List[List[Dict]], cols, seed: int = 0) -> List[Dict]:

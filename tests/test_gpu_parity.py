@@ -363,7 +363,7 @@ def test_every_device_substep_is_the_minimiser_or_says_why(layout):
         for _ in range(12):                                                      # the landing
             env.step(torch.from_numpy(np.tanh(rng.normal(size=(n, 12)) * 0.6).astype(np.float32)).cuda())
         dev = X.DeviceSubsteps(task, env.config, env.model, ter, layout, n, {kk: hb[kk] for kk in ("params", "variant", "box_friction") if kk in hb.arrays})
-        tally, cols = {}, np.arange(n)
+        tally, cols, gaps = {}, np.arange(n), []
         for k in range(steps):
             torch.cuda.synchronize()
             S0 = env.buffers["state"].cpu().numpy()
@@ -377,8 +377,18 @@ def test_every_device_substep_is_the_minimiser_or_says_why(layout):
             for r in X.audit_control_step(ms, hb, ter, S0, fin[abi.S_MOTOR_TARGETS:abi.S_MOTOR_TARGETS + 12], subs, cols, seed=1000 * k):
                 tally[r["cause"]] = tally.get(r["cause"], 0) + 1
                 assert r["cause"] != "unexplained", (task, k, r)
+                if "gap_dev" in r and r["niter"] >= int(ms.iterations) and r["niter_o32"] >= int(ms.iterations):
+                    gaps.append((max(r["gap_dev"], 1e-3), max(r["gap_o32"], 1e-3)))
         print(f"\n[{task} dr={dr} {layout}] every substep of {n * steps} env-steps:", tally)
-        assert tally["minimiser"] > 0.7 * 4 * n * steps and tally.get("cap", 0) + tally.get("edge of W", 0) > 0
+        # the solves BOTH sides cut at the iteration cap from the same input: the device stops NO FURTHER from the minimum than the fp32 oracle does.  (The gap
+        # above the minimum, in fp32 roundings of the cost's terms, spans five decades.  Measured: the device's median is 0.2 - 0.35 decades BELOW the oracle's, it
+        # is better by more than a decade on 10 - 12 % of these solves and worse on 2 % - presumably because the arrowhead factorisation does a fifth of the dense
+        # one's arithmetic, so its Newton directions carry less rounding error; not investigated further.  One-sided bar: a device that converged more slowly than the reference would show here.)
+        lg = np.log10(np.array(gaps))
+        worse, better = float(np.mean(lg[:, 0] > lg[:, 1] + 1)), float(np.mean(lg[:, 1] > lg[:, 0] + 1))
+        print(f"   cut on both sides: {len(gaps)} solves, median log10 gap above the minimum: device {np.median(lg[:, 0]):.2f}, fp32 oracle {np.median(lg[:, 1]):.2f}; "
+              f"device worse by more than a decade on {worse:.1%}, better on {better:.1%}")
+        assert len(gaps) > 50 and np.median(lg[:, 0]) < np.median(lg[:, 1]) + 0.25 and worse < better + 0.05
         dev.close(); env.close()
 
 
