@@ -83,7 +83,7 @@ typedef struct F(OData) {
   R qacc[ONV], efc_force[ONEFC], qfrc_constraint[ONV];
   int solver_niter;
   int solver_niter_max;          /* max over the substeps of env_step */
-  int diag_flags;                /* OR over the substeps of env_step: 1 = stale and fresh rbound pick different pair sets, 2 = a sphere centre inside a box, 4 = the cut was active */
+  int diag_flags;                /* OR over the substeps of env_step: 1 = stale and fresh rbound pick different pair sets, 2 = a sphere centre inside a box, 4 = the cut was active, 8 = a sphere centre on a box surface to 1e-6 */
   R solver_resid, solver_resid_max;   /* scaled gradient norm at the solver's exit (diagnostic: how far from the minimiser the cut solve is) */
   R cacc_base[6];
   R sensordata[49];
@@ -549,6 +549,7 @@ static void F(collision)(const PgttModel* m, const F(OParams)* p, const float* b
                   mx, m->box_solref, m->box_solimp, m->box_margin, m->box_gap, m->box_solmix, c);
     c->geom1 = l; c->geom2 = b; c->foot = l; c->box = b;
     if (c->dist < -(R)m->foot_radius[l]) d->diag_flags |= 2;      /* an ACTIVE contact with the sphere centre inside the box: where the recalled frame flip would bite */
+    if (c->dist < 0 && FABS(c->dist + (R)m->foot_radius[l]) < (R)1e-6) d->diag_flags |= 8;   /* ... ON the surface of the box to 1e-6: the normal is normalize(~0) (the seam attractor) */
   }
 }
 

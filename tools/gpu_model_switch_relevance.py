@@ -6,6 +6,8 @@ rollout, >= 100 k env-steps each after the landing), count the env-steps on whic
       (the fp32 oracle stepped twice from the identical state, switch off / on);
   (b) an ACTIVE foot-box contact has the sphere centre INSIDE the box (dist < -radius) in some substep: where the recalled frame flip of
       _sphere_convex and the frame used here differ;
+  (d) [not a model switch, a property of the reference] an ACTIVE foot-box contact has its sphere centre within 1e-6 of the box SURFACE in some substep:
+      mjx's normal is normalize(closest point - centre) of a zero-length vector there - rounding noise in fp32 (DESIGN.md 3, "the seam attractor");
   (c) the velocity term of the actuator bias (biasprm[2] = -0.5, go2_mjx_feetonly.xml:27), 0.5 |qdot_j|, exceeds 1 % of |actuator force_j| on some joint.
     python tools/gpu_model_switch_relevance.py [n_envs] [steps]          (GPU box; the oracle runs on its host cores)"""
 import os, sys, glob
@@ -23,8 +25,8 @@ NT = os.cpu_count() or 8
 assets = os.path.join(os.path.dirname(mjcf.__file__), "assets", "terrains")
 levels = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(assets, "level*.npy")))
 print(f"# {n} envs x {steps} control steps (after 10 steps of landing) per (policy, level); oracle on {NT} host threads; levels: {levels}")
-print("# policy level | env-steps | cut active | (a) pair sets differ | of those: ACTIVE set differs, state differs (> 1e-6) | (b) centre inside a box | (c) 0.5|qd| > 1 % of |force| ; median over joints of 0.5|qd|/|force|")
-tot = np.zeros(7, np.int64)
+print("# policy level | env-steps | cut active | (a) pair sets differ | of those: ACTIVE set differs, state differs (> 1e-6) | (b) centre inside a box | (c) 0.5|qd| > 1 % of |force| ; median over joints of 0.5|qd|/|force| | (d) env-steps with an ACTIVE foot-box contact whose sphere centre is ON the box surface to 1e-6 (the seam attractor)")
+tot = np.zeros(8, np.int64)
 for policy, method in (("policy177", "pgtt"), ("policy175", "baseline")):
     pi = load_policy(policy)
     for level in levels:
@@ -37,7 +39,7 @@ for policy, method in (("policy177", "pgtt"), ("policy175", "baseline")):
         hs, hf = (oracle.HostBuffers(n, with_variant=True, method=method) for _ in range(2))
         hs["variant"][:] = variant; hf["variant"][:] = variant
         env.reset(7)
-        c = np.zeros(7, np.int64); ratios = []
+        c = np.zeros(8, np.int64); ratios = []
         for k in range(steps + 10):
             a = pi(env.buffers["obs_state"])
             if k >= 10:
@@ -56,10 +58,10 @@ for policy, method in (("policy177", "pgtt"), ("policy175", "baseline")):
             qd = np.abs(hs["state"][:37] - hf["state"][:37]).max(0) > 1e-6
             pair = (fl & 1) != 0
             force = np.abs(hs["frame"][abi.F_ACT_FORCE:abi.F_ACT_FORCE + 12]); bias = 0.5 * np.abs(hs["state"][abi.S_QVEL + 6:abi.S_QVEL + 18])
-            c += np.array([n, int(((fl & 4) != 0).sum()), int(pair.sum()), int((pair & sd).sum()), int((pair & qd).sum()), int(((fl & 2) != 0).sum()), int((bias > 0.01 * force).any(0).sum())])
+            c += np.array([n, int(((fl & 4) != 0).sum()), int(pair.sum()), int((pair & sd).sum()), int((pair & qd).sum()), int(((fl & 2) != 0).sum()), int((bias > 0.01 * force).any(0).sum()), int(((fl & 8) != 0).sum())])
             assert not (sd & ~pair).any() and not (qd & ~pair).any()          # the switch can only act through the pair set
             ratios.append(np.median(bias / np.maximum(force, 1e-6)))
         env.close()
         tot += c
-        print(f"{policy} {level:8s} | {c[0]:7d} | {c[1] / c[0]:7.2%} | {c[2]:6d} ({c[2] / c[0]:.3%}) | {c[3]:5d} {c[4]:5d} | {c[5]:6d} ({c[5] / c[0]:.3%}) | {c[6] / c[0]:7.2%} ; {np.median(ratios):.3f}", flush=True)
-print(f"TOTAL | {tot[0]} env-steps | cut active {tot[1] / tot[0]:.2%} | (a) pair sets differ {tot[2]} ({tot[2] / tot[0]:.4%}), ACTIVE set differs {tot[3]}, state differs {tot[4]} | (b) centre inside {tot[5]} ({tot[5] / tot[0]:.4%}) | (c) {tot[6] / tot[0]:.2%}")
+        print(f"{policy} {level:8s} | {c[0]:7d} | {c[1] / c[0]:7.2%} | {c[2]:6d} ({c[2] / c[0]:.3%}) | {c[3]:5d} {c[4]:5d} | {c[5]:6d} ({c[5] / c[0]:.3%}) | {c[6] / c[0]:7.2%} ; {np.median(ratios):.3f} | seam {c[7]:5d} ({c[7] / c[0]:.3%})", flush=True)
+print(f"TOTAL | {tot[0]} env-steps | cut active {tot[1] / tot[0]:.2%} | (a) pair sets differ {tot[2]} ({tot[2] / tot[0]:.4%}), ACTIVE set differs {tot[3]}, state differs {tot[4]} | (b) centre inside {tot[5]} ({tot[5] / tot[0]:.4%}) | (c) {tot[6] / tot[0]:.2%} | (d) a foot centre ON a box surface to 1e-6 (contact normal = normalize(~0)): {tot[7]} ({tot[7] / tot[0]:.4%})")
