@@ -130,6 +130,32 @@ def test_bias_velocity_switch_against_policy_statistics():
         assert abs(kept[name]["std_ratio"] - 1) < 0.07 and cleared[name]["std_ratio"] > 1.12, (name, kept[name], cleared[name])
 
 
+@pytest.mark.parametrize("name,level", [("policy162", "level7"), ("policy172", "level10"), ("policy182", "level7"), ("policy185", "level10")])
+def test_policy_family_statistics_against_their_own_normalisers(name, level):
+    """The same distribution-level pin from FOUR MORE training runs of the reference (policy_folder/policy162, 172, 182, 185: PGTT policies of three other
+    curriculum series, 2e8 - 8e8 samples each).  Every pickle carries the normaliser of its own run - accumulated over the run's curriculum stages, so each
+    policy is rolled out on the level file where its `scan - min` block matches (profiles/r06_policy_family.txt has all four levels).  With the shipped
+    actuator bias the spreads of gyro / joint positions / joint velocities / last actions / actuator forces sit within 0.90 - 1.11 of the normaliser's and
+    the contact duty within 0.99 - 1.07; with biasprm[2] cleared the joint-velocity spread overshoots to 1.2 - 1.36 on every one of them."""
+    import numpy as np
+    from gpu_policy_stats import compare, rollout_stats
+    from phase_guided_terrain_traversal_amd import mjcf
+    d = np.load(os.path.join(os.path.dirname(mjcf.__file__), "assets", "policies", name + ".npz"))
+    out = {}
+    for kv in (-0.5, 0.0):
+        mean, std = rollout_stats(level, n=1024, steps=500, stochastic=True, kv=kv, policy=name)
+        out[kv] = {r["block"]: r for r in compare(mean, std, d["mean_priv"], d["std_priv"])}
+    kept, cleared = out[-0.5], out[0.0]
+    print(name, level, {k: round(kept[k]["std_ratio"], 3) for k in ("gyro", "joint pos - default", "joint vel", "last action", "actuator force")},
+          "duty", round(kept["last contact"]["mean_here"] / kept["last contact"]["mean_ref"], 3), "scan", round(kept["scan - min"]["mean_here"] / kept["scan - min"]["mean_ref"], 3),
+          "| cleared joint vel", round(cleared["joint vel"]["std_ratio"], 3))
+    assert 0.8 < kept["scan - min"]["mean_here"] / kept["scan - min"]["mean_ref"] < 1.25          # the level file is about the one the run saw on average
+    for k in ("gyro", "joint pos - default", "joint vel", "last action", "actuator force"):
+        assert 0.88 < kept[k]["std_ratio"] < 1.14, (k, kept[k])
+    assert 0.96 < kept["last contact"]["mean_here"] / kept["last contact"]["mean_ref"] < 1.09
+    assert cleared["joint vel"]["std_ratio"] > 1.15 and cleared["joint vel"]["std_ratio"] > kept["joint vel"]["std_ratio"] + 0.2
+
+
 def test_scan_orientation_is_the_one_the_policy_was_trained_with():
     """end-to-end check of the 13 x 9 scan layout (rows front -> back, cols left -> right, go2/heightmap.py:34-65): on level13 the
     reference-trained policy does best with the scan as built - mirrored along either axis or blanked it is slower and falls more
