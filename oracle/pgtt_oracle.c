@@ -377,11 +377,12 @@ BATCH(f32, float)
 BATCH(f64, double)
 
 #define POST(SUF, RT)                                                                                                    \
-  static void post_##SUF(const PgttConfig* cfg, const PgttModel* m, const PgttBuffers* B, const PgttOraclePostIn* in) {  \
+  static void post_##SUF(const PgttConfig* cfg, const PgttModel* m, const PgttBuffers* B, const PgttOraclePostIn* in,    \
+                         uint64_t seed, uint32_t env_id) {                                                               \
     OData_##SUF* d = (OData_##SUF*)calloc(1, sizeof(OData_##SUF)); OInfo_##SUF info; OParams_##SUF p; OEnvCtx_##SUF c;   \
     gather_##SUF(B, 1, 0, d, &info);                                                                                     \
     params_nominal_##SUF(m, &p);                                                                                         \
-    c.cfg = cfg; c.m = m; c.p = &p; c.boxes = NULL; c.box_friction = NULL; c.nbox = 0; c.seed = 0; c.env_id = 0;         \
+    c.cfg = cfg; c.m = m; c.p = &p; c.boxes = NULL; c.box_friction = NULL; c.nbox = 0; c.seed = seed; c.env_id = env_id; \
     static const int lof[4] = {1, 0, 3, 2};                                                                              \
     for (int i = 0; i < 19; i++) d->qpos[i] = (RT)in->qpos[i];                                                           \
     for (int i = 0; i < 18; i++) d->qvel[i] = (RT)in->qvel[i];                                                           \
@@ -408,7 +409,14 @@ BATCH(f64, double)
 POST(f32, float)
 POST(f64, double)
 int pgtt_oracle_task_post(const PgttConfig* cfg, const PgttModel* m, const PgttBuffers* bufs, const PgttOraclePostIn* in, int fp64) {
-  if (fp64) post_f64(cfg, m, bufs, in); else post_f32(cfg, m, bufs, in);
+  if (fp64) post_f64(cfg, m, bufs, in, 0, 0); else post_f32(cfg, m, bufs, in, 0, 0);
+  return 0;
+}
+/* the same with the Philox key of a batch env (seed of the reset, GLOBAL env id): tests/test_gpu_fullsize.py feeds the DEVICE's physics outputs of every
+   env-step of a rollout through the oracle's task layer, noise draws and command resampling included */
+int pgtt_oracle_task_post_ex(const PgttConfig* cfg, const PgttModel* m, const PgttBuffers* bufs, const PgttOraclePostIn* in, int fp64,
+                             uint64_t seed, uint32_t env_id) {
+  if (fp64) post_f64(cfg, m, bufs, in, seed, env_id); else post_f32(cfg, m, bufs, in, seed, env_id);
   return 0;
 }
 

@@ -222,6 +222,72 @@ def test_wrapper_contract_row_by_row_on_a_hand_built_trajectory(observe, golden_
     A.close(); B.close()
 
 
+@pytest.mark.parametrize("method", ["pgtt", "baseline"])
+def test_task_layer_is_the_oracles_on_the_devices_own_physics_every_env_step(method):
+    """A statement about the task layer that needs no W: along a rollout on level4 with observation noise on, the DEVICE's physics outputs of EVERY
+    env-step (qpos, qvel, the 65-row sensor frame, contact flags, the 117 scan heights) go through the oracle's task layer (`pgtt_oracle_task_post_ex`: the
+    code path tests/test_golden_task.py holds to the reference's own vectors) with the env's Philox key, from the device's own `info` rows before the
+    step - and observations (171 + 215; noise draws included), reward, done, the 22 metrics, every `info` row after the step (command resampling, phase,
+    air time, swing peak, H_max / H_min, histories, last contact, the counters) must agree to fp32 rounding.  No solver sits in between, so nothing is
+    amplified: the ~22 % of env-steps outside W are covered like the rest."""
+    import ctypes as C
+    from oracle import oracle
+    from test_golden_task import PostIn
+    n, steps, seed = 256, 60, 11
+    cfg = configs.training_config(method)
+    env, terrain, variant = make(n=n, cfg=cfg, autoreset=False)
+    cs, ms = abi.config_struct(dict(env.config)), abi.model_struct(env.model)
+    od, pd = abi.obs_dims(method)
+    L = oracle.lib()
+    L.pgtt_oracle_task_post_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint32]
+    hb = oracle.HostBuffers(1, method=method)
+    env.reset(seed)
+    worst = {}
+    resampled = 0
+    for k in range(steps):
+        torch.cuda.synchronize()
+        S0, I0 = env.buffers["state"].cpu().numpy(), env.buffers["istate"].cpu().numpy()
+        a = actions(k, n)
+        env.step(a)
+        torch.cuda.synchronize()
+        g = {kk: v.cpu().numpy() for kk, v in env.buffers.items()}
+        act = a.cpu().numpy()
+        Fr = g["frame"]
+        for e in range(n):
+            hb["state"][:, 0] = S0[:, e]; hb["istate"][:, 0] = I0[:, e]
+            pin = PostIn()
+            q = g["state"][:19, e].astype(np.float64)
+            np.ctypeslib.as_array(pin.qpos)[:] = q
+            np.ctypeslib.as_array(pin.qvel)[:] = g["state"][19:37, e]
+            sd = np.zeros(49)
+            sd[0:3] = Fr[abi.F_GYRO:abi.F_GYRO + 3, e]; sd[3:6] = Fr[abi.F_ACCEL:abi.F_ACCEL + 3, e]; sd[6:10] = q[3:7]
+            sd[13:16] = Fr[abi.F_GLOBAL_LINVEL:abi.F_GLOBAL_LINVEL + 3, e]; sd[16:19] = Fr[abi.F_GLOBAL_ANGVEL:abi.F_GLOBAL_ANGVEL + 3, e]
+            sd[19:22] = Fr[abi.F_LOCAL_LINVEL:abi.F_LOCAL_LINVEL + 3, e]; sd[22:25] = Fr[abi.F_UPVECTOR:abi.F_UPVECTOR + 3, e]
+            sd[25:37] = Fr[abi.F_FEET_POS:abi.F_FEET_POS + 12, e]; sd[37:49] = Fr[abi.F_FEET_VEL:abi.F_FEET_VEL + 12, e]
+            np.ctypeslib.as_array(pin.sensordata)[:] = sd
+            mat = np.zeros(9); mat[6:9] = -Fr[abi.F_GRAVITY:abi.F_GRAVITY + 3, e]          # the task layer reads the IMU frame's third row only (gravity)
+            np.ctypeslib.as_array(pin.site_imu_mat)[:] = mat
+            np.ctypeslib.as_array(pin.site_foot_z)[:] = Fr[abi.F_FOOT_SITE_Z:abi.F_FOOT_SITE_Z + 4, e]
+            np.ctypeslib.as_array(pin.actuator_force)[:] = Fr[abi.F_ACT_FORCE:abi.F_ACT_FORCE + 12, e]
+            np.ctypeslib.as_array(pin.action)[:] = act[e]
+            np.ctypeslib.as_array(pin.scan_z)[:] = g["scan_z"][e]
+            np.ctypeslib.as_array(pin.contact)[:] = Fr[abi.F_CONTACT:abi.F_CONTACT + 4, e].astype(np.int32)
+            b = hb.struct()
+            L.pgtt_oracle_task_post_ex(C.byref(cs), C.byref(ms), C.byref(b), C.byref(pin), 0, C.c_uint64(seed), C.c_uint32(e))
+            errs = dict(obs=np.abs(hb["obs_state"][0] - g["obs_state"][e]).max(), priv=np.abs(hb["obs_priv"][0] - g["obs_priv"][e]).max(),
+                        reward=abs(float(hb["reward"][0]) - float(g["reward"][e])), metrics=(np.abs(hb["metrics"][:, 0] - g["metrics"][:, e]) / (1 + np.abs(hb["metrics"][:, 0]))).max(),
+                        info=np.abs(hb["state"][abi.S_CMD:, 0] - g["state"][abi.S_CMD:, e]).max())
+            for kk, v in errs.items():
+                worst[kk] = max(worst.get(kk, 0.0), float(v))
+            assert errs["obs"] < 1e-5 and errs["priv"] < 2e-5 and errs["reward"] < 1e-6 and errs["metrics"] < 1e-5 and errs["info"] < 1e-6, (k, e, errs)      # measured: 1.9e-6 / 1.9e-6 / 4e-9 / 1e-7 / 6e-8
+            assert hb["done"][0] == g["done"][e] and np.array_equal(hb["istate"][:3, 0], g["istate"][:3, e]), (k, e)
+            resampled += int(not np.array_equal(S0[abi.S_CMD:abi.S_CMD + 3, e], g["state"][abi.S_CMD:abi.S_CMD + 3, e]))
+    assert resampled >= 10                                      # sample_command's resampling branch was met (timer ~ Exp(5 s))
+    print(f"\n[{method}] {n * steps} env-steps, worst |device - oracle task layer on the device's physics|:", {kk: f"{v:.2e}" for kk, v in worst.items()}, "commands resampled:", resampled)
+    assert od == g["obs_state"].shape[1] and pd == g["obs_priv"].shape[1]
+    env.close()
+
+
 def _tops(boxes, pts):
     """analytic terrain height under (x, y) for yaw-only boxes resting on z = 0"""
     top = np.zeros(len(pts))
