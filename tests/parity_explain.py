@@ -209,6 +209,28 @@ def audit_substep(ms, ms_long, ed: EnvData, inp, ctrl, sub: Dict, seed: int = 0)
     return out
 
 
+def euler_error(ms, inp, sub: Dict) -> float:
+    """mjx's semi-implicit Euler step (eulerdamp disabled, go2_mjx_feetonly.xml:18) from the substep's input and the DEVICE's acceleration, in fp64, against
+    the state the device integrated to -> largest |difference| / (1 + |value|) over qvel' and qpos' (free-joint quaternion: q (x) exp(dt w / 2), normalised)"""
+    dt = float(ms.timestep)
+    qpos, qvel = np.asarray(inp[0], np.float64), np.asarray(inp[1], np.float64)
+    a = np.asarray(sub["qacc"], np.float64)
+    v = qvel + dt * a
+    q = qpos.copy()
+    q[:3] += dt * v[:3]; q[7:] += dt * v[6:]
+    w = v[3:6]; nn = np.linalg.norm(w)
+    if nn > 1e-8:      # math.normalize_with_norm leaves (near-)zero vectors alone
+        ax, ang = w / nn, dt * nn
+        r = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * ax])
+        u = qpos[3:7]
+        q[3:7] = [u[0]*r[0] - u[1]*r[1] - u[2]*r[2] - u[3]*r[3], u[0]*r[1] + u[1]*r[0] + u[2]*r[3] - u[3]*r[2],
+                  u[0]*r[2] - u[1]*r[3] + u[2]*r[0] + u[3]*r[1], u[0]*r[3] + u[1]*r[2] - u[2]*r[1] + u[3]*r[0]]
+    q[3:7] /= np.linalg.norm(q[3:7])
+    ev = np.abs(np.asarray(sub["qvel"], np.float64) - v) / (1 + np.abs(v))
+    eq = np.abs(np.asarray(sub["qpos"], np.float64) - q) / (1 + np.abs(q))
+    return float(max(ev.max(), eq.max()))
+
+
 def audit_control_step(ms, hb, terrain, S0: np.ndarray, ctrl_rows: np.ndarray, dev: List[List[Dict]], cols, seed: int = 0) -> List[Dict]:
     """audit_substep over every substep of the envs `cols` (dev = the device's substeps of exactly those envs) -> records {env, substep, cause, detail}"""
     ms_long = model_copy(ms, iterations=LONG_ITER, ls_iterations=LONG_LS)
@@ -219,7 +241,7 @@ def audit_control_step(ms, hb, terrain, S0: np.ndarray, ctrl_rows: np.ndarray, d
         inp = (S0[:19, e].astype(np.float64), S0[19:37, e].astype(np.float64), S0[37:55, e].astype(np.float64))
         for s_, sub in enumerate(dev[i]):
             v = audit_substep(ms, ms_long, ed, inp, ctrl_rows[:, e].astype(np.float64), sub, seed=seed + 4 * e + s_)
-            out.append(dict(env=e, substep=s_, niter=int(sub["niter"]), **v))
+            out.append(dict(env=e, substep=s_, niter=int(sub["niter"]), euler=euler_error(ms, inp, sub), **v))
             inp = (sub["qpos"].astype(np.float64), sub["qvel"].astype(np.float64), sub["qacc"].astype(np.float64))
     return out
 

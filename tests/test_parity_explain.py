@@ -109,5 +109,6 @@ def test_every_substep_of_a_second_fp32_build_is_the_minimiser_or_says_why():
         for r in X.audit_control_step(ms, a, terrain, S0, ctrl, subs(cols, S0, act, ctrl, 4), cols, seed=1000 * k):
             tally[r["cause"]] = tally.get(r["cause"], 0) + 1
             assert r["cause"] != "unexplained", r
+            assert r["euler"] < 5e-7, r
     print("\nevery substep of", n * steps, "env-steps:", tally)
     assert tally["minimiser"] > 0.7 * 4 * n * steps and tally.get("cap", 0) > 0
