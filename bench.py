@@ -221,6 +221,8 @@ def timed_window(env, n, steps, warmup, dev, rank, world, stub, sync, prime_step
     # roll-out - busy.  A gap of host-bound work here (event read-back, the eight timed reductions above) used to let it clock down just
     # before the clock started: a 20-step window then read physics_kernel at 180 us against 168 us in the 300-step window.
     env.enable_timing(8)          # every 8th step: an event record costs a few us of GPU idle
+    import gc
+    gc.collect(); gc_was = gc.isenabled(); gc.disable()          # no collection from here to the end of the timed window (see below)
     run(0, (100 if stub else prime_steps) + warmup)
     sums.zero_(); reducer.reduce(); env_steps_seen.zero_()               # counters back to zero (enqueued behind the warm-up steps)
     # timing counters back to zero: means are over the timed steps only - steps 4, 12, 20, ... of a long window, three steps of a short one
@@ -229,10 +231,18 @@ def timed_window(env, n, steps, warmup, dev, rank, world, stub, sync, prime_step
     if world > 1:
         dist.barrier()
     sync()
+    # The window opens on an EMPTY queue (the contract's synchronize): for its first ~100 us the device runs only as far ahead as the host has launched,
+    # so a host pause there - a generation-2 garbage collection, a preemption - is device idle time inside a 3.7 ms window (seen once in five runs of the
+    # driver's command: 0.45 ms, 19.5 M instead of 21.8 - 22.4 M with every side row of the same line at its usual value).  No collection inside the window
+    # (what `timeit` does).  (A real-time priority for the launching thread was considered and left out: a spinning FIFO thread can starve the runtime's own
+    # helper threads.)  The collector is switched off before the priming steps above (a collection right here would be 10 - 50 ms of device idle time in
+    # front of the window - the clocks drop) and back on behind the window.
     t0 = time.perf_counter()
     run(0, steps)
     sync()
     dt_own = time.perf_counter() - t0          # this rank's own K steps done (before it waits for the others)
+    if gc_was:
+        gc.enable()
     if world > 1:
         dist.barrier()
     sync()
