@@ -34,7 +34,11 @@ def source_sha256() -> str:
 def build_info(path: Optional[str] = None) -> dict:
     """What the library says it was built from: {"src": <source_sha256 at build time>, "flavor": "product" | "fastdiv" | "flip" | ...}
     (pgtt_build_info(), no GPU needed)."""
-    L = C.CDLL(path or LIB_PATH) if (path or _LIB is None) else _LIB
+    if path or _LIB is None:
+        import torch  # noqa: F401  (same order as lib(): torch's HIP runtime first, or a later torch.cuda in this process finds no GPU)
+        L = C.CDLL(path or LIB_PATH)
+    else:
+        L = _LIB
     L.pgtt_build_info.restype = C.c_char_p
     return dict(kv.split("=", 1) for kv in L.pgtt_build_info().decode().split(";"))
 

@@ -27,7 +27,6 @@ np.set_printoptions(precision=6, linewidth=220, suppress=True)
 ml = X.model_copy(ms, iterations=X.LONG_ITER, ls_iterations=X.LONG_LS)
 out = {}
 for i, e in enumerate(envs):
-    hb = {"variant": opt.get("variant")}
     boxes = None if terrain is None else terrain[int(opt["variant"][e]) if "variant" in opt else 0]
     kw = dict(boxes=boxes, box_friction=opt["box_friction"][:, e] if "box_friction" in opt else None, params=opt["params"][:, e] if "params" in opt else None)
     inp = (S0[:19, e].astype(float), S0[19:37, e].astype(float), S0[37:55, e].astype(float))
